@@ -1,0 +1,272 @@
+// Python bindings of the gfx950 kernel suite and the step-program runtime.
+//
+// Tensors cross the boundary as raw device addresses (tensor.data_ptr()) and streams as raw
+// hipStream_t handles (torch.cuda.current_stream().cuda_stream); shape checking and output
+// allocation live in distributed_tensorflow_amd/ops. Every kernel takes a keyword dictionary
+// that is copied field by field into the kernel's argument struct, so unspecified fields are
+// zero / null.
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include "kernels/conv.h"
+#include "kernels/ops.h"
+#include "runtime/program.h"
+
+namespace py = pybind11;
+using namespace dtf;
+
+namespace {
+
+template <typename T>
+T* as_ptr(const py::dict& d, const char* key) {
+  if (!d.contains(key)) return nullptr;
+  py::object o = d[key];
+  if (o.is_none()) return nullptr;
+  return reinterpret_cast<T*>(o.cast<uint64_t>());
+}
+
+template <typename T>
+void get(const py::dict& d, const char* key, T& out) {
+  if (d.contains(key) && !d[key].is_none()) out = d[key].cast<T>();
+}
+
+BnRef as_bn(const py::dict& d, const char* key) {
+  BnRef b{nullptr, nullptr, nullptr, 0.f, 0.f};
+  if (!d.contains(key) || d[key].is_none()) return b;
+  py::tuple t = d[key].cast<py::tuple>();
+  b.sums = reinterpret_cast<const double*>(t[0].cast<uint64_t>());
+  b.gamma = reinterpret_cast<const float*>(t[1].cast<uint64_t>());
+  b.beta = reinterpret_cast<const float*>(t[2].cast<uint64_t>());
+  b.inv_count = t[3].cast<float>();
+  b.eps = t[4].cast<float>();
+  return b;
+}
+
+hipStream_t as_stream(uint64_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define P(field, T) a.field = as_ptr<T>(d, #field)
+#define V(field) get(d, #field, a.field)
+
+}  // namespace
+
+PYBIND11_MODULE(_hip, m) {
+  m.doc() = "gfx950 HIP kernels and step-program runtime";
+
+  m.def("device_count", []() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+  });
+
+  // ---------------------------------------------------------------- convolution
+  m.def("conv_fprop", [](const py::dict& d, int ks, uint64_t stream) {
+    ConvFpropArgs a{};
+    P(in, const float); P(wpk, const float); P(out, float);
+    V(B); V(H); V(W); V(Cin); V(Ho); V(Wo); V(Cout);
+    V(TH); V(TW); V(tiles_y); V(tiles_x);
+    V(pad); V(stride); V(upsample); V(nt_total);
+    V(in_mode); a.in_bn = as_bn(d, "in_bn");
+    V(res_mode); P(res, const float); a.res_bn = as_bn(d, "res_bn");
+    V(epi_mode); P(bias, const float); P(mask_src, const float); a.mask_bn = as_bn(d, "mask_bn");
+    P(extra, const float); P(out_sums, double);
+    if (a.stride == 0) a.stride = 1;
+    return conv_fprop(a, ks, as_stream(stream));
+  });
+  m.def("pack_conv_weights", [](uint64_t w, uint64_t out, int ks, int Cin, int Cout, int flip, uint64_t stream) {
+    PackArgs a{reinterpret_cast<const float*>(w), reinterpret_cast<float*>(out), ks, Cin, Cout, flip};
+    pack_conv_weights(a, as_stream(stream));
+  });
+  m.def("packed_weight_floats", &packed_weight_floats);
+  m.def("conv_wgrad", [](const py::dict& d, int ks, uint64_t stream) {
+    ConvWgradArgs a{};
+    P(in, const float); P(dout, const float); P(dw, float);
+    V(B); V(H); V(W); V(Cin); V(Ho); V(Wo); V(Cout);
+    V(TH); V(TW); V(tiles_y); V(tiles_x);
+    V(pad); V(stride); V(in_mode); a.in_bn = as_bn(d, "in_bn");
+    V(tiles_per_block);
+    if (a.stride == 0) a.stride = 1;
+    return conv_wgrad(a, ks, as_stream(stream));
+  });
+  m.def("pack_multi", [](uint64_t params, uint64_t packed, uint64_t table, int n_entries, int total_blocks,
+                         uint64_t stream) {
+    PackMultiArgs a{reinterpret_cast<const float*>(params), reinterpret_cast<float*>(packed),
+                    reinterpret_cast<const PackEntry*>(table), n_entries};
+    pack_multi(a, total_blocks, as_stream(stream));
+  });
+  m.attr("PACK_ENTRY_BYTES") = (int)sizeof(PackEntry);
+
+  // ---------------------------------------------------------------- batch norm
+  m.def("bn_stats", [](const py::dict& d, uint64_t stream) {
+    BnStatsArgs a{};
+    P(x, const float); P(sums, double); V(n_rows); V(C);
+    bn_stats(a, as_stream(stream));
+  });
+  m.def("bn_apply", [](const py::dict& d, uint64_t stream) {
+    BnApplyArgs a{};
+    P(x, const float); P(y, float); a.bn = as_bn(d, "bn"); V(n_rows); V(C); V(relu);
+    bn_apply(a, as_stream(stream));
+  });
+  m.def("bn_relu_bwd_reduce", [](const py::dict& d, uint64_t stream) {
+    BnReluBwdReduceArgs a{};
+    P(dy, const float); P(x, const float); P(g, float); a.bn = as_bn(d, "bn"); P(gsums, double);
+    V(n_rows); V(C); V(relu);
+    bn_relu_bwd_reduce(a, as_stream(stream));
+  });
+  m.def("bn_bwd_apply", [](const py::dict& d, uint64_t stream) {
+    BnBwdApplyArgs a{};
+    P(g, const float); P(x, const float); P(dx, float); a.bn = as_bn(d, "bn"); P(gsums, const double);
+    P(dgamma, float); P(dbeta, float); V(n_rows); V(C); V(res_mode); P(res, const float); V(H); V(W);
+    bn_bwd_apply(a, as_stream(stream));
+  });
+
+  // ---------------------------------------------------------------- head / loss
+  m.def("head_fwd", [](const py::dict& d, uint64_t stream) {
+    HeadFwdArgs a{};
+    P(x, const float); a.bn = as_bn(d, "bn"); P(fc_w, const float); P(fc_b, const float); P(labels, const int);
+    P(feat, float); P(logits, float); P(dlogits, float); P(loss, float); P(correct, int);
+    V(B); V(HW); V(C); V(K);
+    head_fwd(a, as_stream(stream));
+  });
+  m.def("head_bwd", [](const py::dict& d, uint64_t stream) {
+    HeadBwdArgs a{};
+    P(x, const float); a.bn = as_bn(d, "bn"); P(fc_w, const float); P(feat, const float); P(dlogits, const float);
+    P(g, float); P(gsums, double); P(d_fc_w, float); P(d_fc_b, float);
+    V(B); V(HW); V(C); V(K);
+    head_bwd(a, as_stream(stream));
+  });
+  m.def("softmax_xent", [](const py::dict& d, uint64_t stream) {
+    SoftmaxXentArgs a{};
+    P(logits, const float); P(labels, const int); P(dlogits, float); P(loss, float); P(correct, int); V(B); V(K);
+    softmax_xent(a, as_stream(stream));
+  });
+  m.def("top1_count", [](const py::dict& d, uint64_t stream) {
+    Top1Args a{};
+    P(logits, const float); P(labels, const int); P(correct, int); V(B); V(K);
+    top1_count(a, as_stream(stream));
+  });
+
+  // ---------------------------------------------------------------- optimizers / flat
+  m.def("fused_adam", [](const py::dict& d, uint64_t stream) {
+    FlatOptArgs a{};
+    P(p, float); P(g, const float); P(m, float); P(v, float); P(hyper, const float); V(n);
+    fused_adam(a, as_stream(stream));
+  });
+  m.def("fused_momentum_sgd", [](const py::dict& d, uint64_t stream) {
+    FlatOptArgs a{};
+    P(p, float); P(g, const float); P(m, float); P(hyper, const float); V(n);
+    fused_momentum_sgd(a, as_stream(stream));
+  });
+  m.def("flat_scale", [](const py::dict& d, uint64_t stream) {
+    FlatScaleArgs a{};
+    P(x, float); P(scale_dev, const float); a.scale = 1.f; V(scale); V(n);
+    flat_scale(a, as_stream(stream));
+  });
+  m.def("flat_axpy", [](const py::dict& d, uint64_t stream) {
+    AxpyArgs a{};
+    P(y, float); P(x, const float); V(alpha); V(n);
+    flat_axpy(a, as_stream(stream));
+  });
+  m.def("memset", [](uint64_t dst, int value, uint64_t bytes, uint64_t stream) {
+    memset_async(reinterpret_cast<void*>(dst), value, bytes, as_stream(stream));
+  });
+  m.def("memcpy_d2d", [](uint64_t dst, uint64_t src, uint64_t bytes, uint64_t stream) {
+    memcpy_async(reinterpret_cast<void*>(dst), reinterpret_cast<const void*>(src), bytes, as_stream(stream));
+  });
+
+  // ---------------------------------------------------------------- elementwise & friends
+  m.def("add_relu_fwd", [](const py::dict& d, uint64_t stream) {
+    AddReluArgs a{};
+    P(a, const float); P(b, const float); P(out, float); V(n); V(relu_first);
+    add_relu_fwd(a, as_stream(stream));
+  });
+  m.def("add_relu_bwd", [](const py::dict& d, uint64_t stream) {
+    AddReluBwdArgs a{};
+    P(dout, const float); P(a, const float); P(b, const float); P(da, float); P(db, float); V(n); V(relu_first);
+    add_relu_bwd(a, as_stream(stream));
+  });
+  m.def("relu_bwd", [](const py::dict& d, uint64_t stream) {
+    ReluMaskArgs a{};
+    P(dy, const float); P(y, const float); P(dx, float); V(n);
+    relu_bwd(a, as_stream(stream));
+  });
+  m.def("shortcut_a_fwd", [](const py::dict& d, uint64_t stream) {
+    ShortcutAArgs a{};
+    P(x, const float); P(y, float); V(B); V(H); V(W); V(C);
+    shortcut_a_fwd(a, as_stream(stream));
+  });
+  m.def("shortcut_a_bwd", [](const py::dict& d, uint64_t stream) {
+    ShortcutABwdArgs a{};
+    P(dy, const float); P(dx, float); V(B); V(H); V(W); V(C); V(accumulate);
+    shortcut_a_bwd(a, as_stream(stream));
+  });
+  m.def("maxpool2x2_fwd", [](const py::dict& d, uint64_t stream) {
+    MaxPoolArgs a{};
+    P(x, const float); P(y, float); P(argmax, unsigned char); V(B); V(H); V(W); V(C);
+    maxpool2x2_fwd(a, as_stream(stream));
+  });
+  m.def("maxpool2x2_bwd", [](const py::dict& d, uint64_t stream) {
+    MaxPoolBwdArgs a{};
+    P(dy, const float); P(argmax, const unsigned char); P(y, const float); P(dx, float);
+    V(B); V(H); V(W); V(C); V(relu_mask);
+    maxpool2x2_bwd(a, as_stream(stream));
+  });
+  m.def("dropout", [](const py::dict& d, uint64_t stream) {
+    DropoutArgs a{};
+    P(x, const float); P(y, float); V(n); V(keep_prob); V(seed); V(offset);
+    dropout_apply(a, as_stream(stream));
+  });
+  m.def("gemm_f32", [](const py::dict& d, uint64_t stream) {
+    GemmArgs a{};
+    P(A, const float); P(B, const float); P(C, float); P(bias, const float);
+    V(M); V(N); V(K); V(lda); V(ldb); V(ldc); V(trans_a); V(trans_b); V(relu); V(accumulate);
+    gemm_f32(a, as_stream(stream));
+  });
+  m.def("col_sum", [](const py::dict& d, uint64_t stream) {
+    ColSumArgs a{};
+    P(x, const float); P(out, float); V(n_rows); V(C);
+    col_sum(a, as_stream(stream));
+  });
+  m.def("zero_count", [](const py::dict& d, uint64_t stream) {
+    ZeroFracArgs a{};
+    P(x, const float); P(zeros, unsigned long long); V(n);
+    zero_count(a, as_stream(stream));
+  });
+  m.def("crop_whiten", [](const py::dict& d, uint64_t stream) {
+    CropWhitenArgs a{};
+    P(src, const float); P(index, const int); P(offs, const int); P(out, float);
+    V(B); V(HP); V(WP); V(H); V(W); V(C); V(whiten);
+    crop_whiten(a, as_stream(stream));
+  });
+
+  // ---------------------------------------------------------------- step programs
+  py::class_<Program>(m, "Program")
+      .def(py::init<>())
+      .def("begin_record", [](Program& p) {
+        if (current_recorder()) throw std::runtime_error("a Program is already recording on this thread");
+        current_recorder() = &p;
+      })
+      .def("end_record", [](Program& p) {
+        if (current_recorder() != &p) throw std::runtime_error("this Program is not recording");
+        current_recorder() = nullptr;
+      })
+      .def("mark_segment", &Program::mark_segment)
+      .def_property_readonly("num_segments", &Program::num_segments)
+      .def_property_readonly("num_records", [](const Program& p) { return p.records.size(); })
+      .def("record_names", [](const Program& p) {
+        std::vector<std::string> v;
+        for (auto& r : p.records) v.push_back(r.name);
+        return v;
+      })
+      .def("segment_bounds", [](const Program& p) { return p.seg_begin; })
+      .def("run", [](const Program& p, uint64_t stream, int seg) {
+        py::gil_scoped_release rel;
+        p.run(as_stream(stream), seg);
+      }, py::arg("stream"), py::arg("seg") = -1)
+      .def("instantiate", [](Program& p, uint64_t stream, int seg) { p.instantiate(as_stream(stream), seg); },
+           py::arg("stream"), py::arg("seg") = -1)
+      .def("instantiated", &Program::instantiated, py::arg("seg") = -1)
+      .def("replay", [](const Program& p, uint64_t stream, int seg) {
+        py::gil_scoped_release rel;
+        p.replay(as_stream(stream), seg);
+      }, py::arg("stream"), py::arg("seg") = -1);
+}

@@ -1,0 +1,58 @@
+// Shared device/host helpers for the gfx950 (CDNA4) kernel suite.
+//
+// Conventions used by every kernel in this directory:
+//   * activations are NHWC fp32, conv filters HWIO fp32 (TensorFlow-native layouts, so a
+//     checkpoint tensor is the in-memory tensor);
+//   * a wavefront is 64 lanes; blocks are 256 threads (4 waves, one per SIMD);
+//   * GEMM-shaped work runs on the exact-fp32 matrix instruction v_mfma_f32_16x16x4_f32:
+//       A operand: lane l holds A[row = l & 15][k = l >> 4]
+//       B operand: lane l holds B[k = l >> 4][col = l & 15]
+//       C/D      : lane l, register r holds D[row = 4 * (l >> 4) + r][col = l & 15]
+//   * per-channel BatchNorm statistics travel as a block of 2*C doubles: sum then sum of
+//     squares, accumulated by the producing kernel's epilogue with fp64 atomics.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#define DTF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+namespace dtf {
+
+// Reference to one BatchNorm layer's batch statistics and affine parameters.
+struct BnRef {
+  const double* sums;   // [2*C]: per-channel sum, then per-channel sum of squares
+  const float* gamma;   // [C]
+  const float* beta;    // [C]
+  float inv_count;      // 1 / (B*H*W)
+  float eps;
+};
+
+// scale/shift such that bn(x) = x*scale + shift, plus mean/rstd for the backward pass.
+__device__ __forceinline__ void bn_coeffs(const BnRef& bn, int c, int C, float& scale, float& shift,
+                                          float& mean_f, float& rstd_f) {
+  double mean = bn.sums[c] * (double)bn.inv_count;
+  double var = bn.sums[C + c] * (double)bn.inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  float rstd = rsqrtf((float)var + bn.eps);
+  float g = bn.gamma[c];
+  scale = g * rstd;
+  shift = bn.beta[c] - (float)mean * scale;
+  mean_f = (float)mean;
+  rstd_f = rstd;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace dtf
+
+// Launch plumbing: every host-side launcher goes through dtf::launch so that a recording
+// Program (csrc/runtime/program.h) can capture the launch instead of issuing it.
+#include "../runtime/program.h"

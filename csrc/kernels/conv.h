@@ -1,0 +1,82 @@
+// Host API of the implicit-GEMM convolution kernels (NHWC activations, HWIO filters, fp32).
+//
+// The reference obtains these from TensorFlow's conv2d / conv2d_backprop_{input,filter} ops
+// (reference: DistributedResNet/src/resnet.py:99,121,150 and DistributedLeNet/src/mnist.py:107-123).
+#pragma once
+#include "common.h"
+
+namespace dtf {
+
+enum InMode : int { IN_RAW = 0, IN_BNRELU = 1 };
+enum ResMode : int { RES_NONE = 0, RES_IDENT = 1, RES_BNRELU = 2, RES_SHORTCUT_A = 3 };
+enum EpiMode : int { EPI_PLAIN = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2, EPI_BIAS = 3 };
+
+// One forward-shaped convolution: out = conv(in', W) [+ residual] with optional fused
+// prologue (in' = relu(bn(in))) and epilogues. Also serves as the data-gradient kernel:
+// dgrad of a stride-1 conv is a stride-1 conv with flipped/transposed filters, dgrad of a
+// stride-2 conv is the same over the zero-upsampled gradient (`upsample`=1).
+struct ConvFpropArgs {
+  const float* in;    // [B,H,W,Cin]
+  const float* wpk;   // packed filters, see pack_conv_weights
+  float* out;         // [B,Ho,Wo,Cout]
+  int B, H, W, Cin;
+  int Ho, Wo, Cout;
+  int TH, TW, tiles_y, tiles_x;  // output tile and tile grid per image
+  int pad;                       // rows/cols of implicit zero padding before the input
+  int stride;                    // 1 or 2 (must match the template instance)
+  int upsample;                  // 1: `in` is read as if zero-upsampled by 2 (stride-2 dgrad)
+  int nt_total;                  // 16-channel output tiles in the packed filter (= ceil(Cout/16))
+  // prologue
+  int in_mode;
+  BnRef in_bn;
+  // residual (forward)
+  int res_mode;
+  const float* res;  // RES_IDENT/RES_BNRELU: [B,Ho,Wo,Cout]; RES_SHORTCUT_A: [B,2Ho,2Wo,Cout/2]
+  BnRef res_bn;
+  // epilogue
+  int epi_mode;
+  const float* bias;      // EPI_BIAS_RELU / EPI_BIAS: [Cout]
+  const float* mask_src;  // EPI_MASK: x such that the mask is bn(x) > 0, [B,Ho,Wo,Cout]
+  BnRef mask_bn;
+  const float* extra;     // EPI_MASK: optional gradient added before masking, [B,Ho,Wo,Cout]
+  // statistics accumulated over the written tensor (nullable): for forward the per-channel
+  // sum and sum of squares of `out`; for EPI_MASK the sums of g and g*xhat.
+  double* out_sums;
+};
+
+// ks in {3,5}; cin_pad in {4,16,32,64}; launches over all B images.
+// Returns the dynamic LDS bytes used (for reporting), throws on unsupported shapes.
+size_t conv_fprop(const ConvFpropArgs& a, int ks, hipStream_t stream);
+// Picks (TH, TW, tiles, cout split) for the given problem; fills the tiling fields of `a`.
+void conv_fprop_plan(ConvFpropArgs& a, int ks);
+
+// Packs HWIO filters [ks,ks,Cin,Cout] into the MFMA B-operand layout
+//   packed[kgroup][ntile][lane 0..63][4]
+// `transpose_flip`=1 packs the data-gradient filter W'[kh][kw][co][ci] = W[ks-1-kh][ks-1-kw][ci][co].
+struct PackArgs {
+  const float* w;
+  float* out;
+  int ks, Cin, Cout;   // of the forward filter
+  int transpose_flip;
+};
+void pack_conv_weights(const PackArgs& a, hipStream_t stream);
+size_t packed_weight_floats(int ks, int Cin, int Cout, int transpose_flip);
+
+// Filter gradient: dW[kh,kw,ci,co] += sum_{n,y,x} act(in)[n, y*s+kh-pad, x*s+kw-pad, ci] * dout[n,y,x,co]
+// accumulated with fp32 atomics into `dw` (HWIO), which the caller zeroes beforehand.
+struct ConvWgradArgs {
+  const float* in;     // [B,H,W,Cin]
+  const float* dout;   // [B,Ho,Wo,Cout]
+  float* dw;           // [ks,ks,Cin,Cout]
+  int B, H, W, Cin;
+  int Ho, Wo, Cout;
+  int TH, TW, tiles_y, tiles_x;
+  int pad, stride;
+  int in_mode;
+  BnRef in_bn;
+  int tiles_per_block;   // tiles of the flattened (image, tile) sequence walked by one block
+  float* dbias;          // nullable: [Cout] += sum of dout (LeNet bias gradient)
+};
+size_t conv_wgrad(ConvWgradArgs a, int ks, hipStream_t stream);
+
+}  // namespace dtf

@@ -1,0 +1,146 @@
+// fp32 GEMM on the exact-fp32 matrix cores (fully connected layers of LeNet).
+//
+// C[M,N] = op(A)[M,K] * op(B)[K,N] (+ bias[N]) (ReLU). 64x64 block tile, 16-deep k-step, four
+// waves each owning a 32x32 quadrant as 2x2 MFMA 16x16x4 tiles. Both operand tiles are stored
+// k-contiguous in LDS ([row][k] and [col][k], rows padded by 4 floats) so that one
+// ds_read_b128 per operand feeds four MFMAs, using the same k-permutation as the conv kernels.
+// Small-M problems (batch-sized M) are split along K across blocks to fill the 256 CUs; the
+// partial products are combined with fp32 atomics and bias/ReLU run as a second tiny pass.
+// (reference ops: tf.matmul in DistributedLeNet/src/mnist.py:136,145)
+#include "ops.h"
+
+namespace dtf {
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 16, LDT = BK + 4;
+
+struct GemmKArgs {
+  GemmArgs g;
+  int k_per_split;
+  int atomic_out;
+};
+
+__global__ __launch_bounds__(256) void gemm_kernel(GemmKArgs ka) {
+  const GemmArgs& a = ka.g;
+  __shared__ __attribute__((aligned(16))) float As[BM * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, l15 = lane & 15;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int k_begin = blockIdx.z * ka.k_per_split;
+  int k_end = k_begin + ka.k_per_split;
+  if (k_end > a.K) k_end = a.K;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+
+  floatx4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = floatx4{0, 0, 0, 0};
+
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+    // stage A tile [BM][BK] and B tile [BN][BK]; 1024 elements each, 4 per thread
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int e = tid + it * 256;
+      {
+        int r, kk;
+        if (a.trans_a) { r = e & 63; kk = e >> 6; } else { kk = e & 15; r = e >> 4; }
+        const int m = m0 + r, k = k0 + kk;
+        float v = 0.f;
+        if (m < a.M && k < k_end) v = a.trans_a ? a.A[(size_t)k * a.lda + m] : a.A[(size_t)m * a.lda + k];
+        As[r * LDT + kk] = v;
+      }
+      {
+        int c, kk;
+        if (a.trans_b) { kk = e & 15; c = e >> 4; } else { c = e & 63; kk = e >> 6; }
+        const int n = n0 + c, k = k0 + kk;
+        float v = 0.f;
+        if (n < a.N && k < k_end) v = a.trans_b ? a.B[(size_t)n * a.ldb + k] : a.B[(size_t)k * a.ldb + n];
+        Bs[c * LDT + kk] = v;
+      }
+    }
+    __syncthreads();
+    floatx4 av[2], bv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const floatx4*>(&As[(wm + i * 16 + l15) * LDT + 4 * q]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const floatx4*>(&Bs[(wn + j * 16 + l15) * LDT + 4 * q]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = DTF_MFMA16(av[i][s], bv[j][s], acc[i][j]);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + i * 16 + 4 * q + r;
+        const int n = n0 + wn + j * 16 + l15;
+        if (m >= a.M || n >= a.N) continue;
+        float v = acc[i][j][r];
+        float* dst = a.C + (size_t)m * a.ldc + n;
+        if (ka.atomic_out) {
+          atomicAdd(dst, v);
+        } else {
+          if (a.bias) v += a.bias[n];
+          if (a.accumulate) v += *dst;
+          if (a.relu) v = fmaxf(v, 0.f);
+          *dst = v;
+        }
+      }
+}
+
+struct BiasActArgs { float* C; const float* bias; int M, N, ldc, relu; };
+__global__ __launch_bounds__(256) void bias_act_kernel(BiasActArgs a) {
+  const long long total = (long long)a.M * a.N;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int n = (int)(i % a.N);
+    const long long m = i / a.N;
+    float v = a.C[m * a.ldc + n];
+    if (a.bias) v += a.bias[n];
+    if (a.relu) v = fmaxf(v, 0.f);
+    a.C[m * a.ldc + n] = v;
+  }
+}
+
+}  // namespace
+
+void gemm_f32(const GemmArgs& a, hipStream_t stream) {
+  const int gx = ceil_div(a.N, BN), gy = ceil_div(a.M, BM);
+  int splits = 1;
+  const int k_steps = ceil_div(a.K, BK);
+  while (gx * gy * splits < 256 && splits * 2 <= k_steps / 4 && splits < 32) splits *= 2;
+  GemmKArgs ka;
+  ka.g = a;
+  ka.k_per_split = ceil_div(k_steps, splits) * BK;
+  ka.atomic_out = splits > 1;
+  if (splits > 1) {
+    if (!a.accumulate) {
+      if (a.ldc == a.N) {
+        memset_async(a.C, 0, (size_t)a.M * a.N * sizeof(float), stream);
+      } else {
+        for (int m = 0; m < a.M; ++m) memset_async(a.C + (size_t)m * a.ldc, 0, (size_t)a.N * sizeof(float), stream);
+      }
+    }
+    launch("gemm_f32_splitk", gemm_kernel, dim3(gx, gy, splits), dim3(256), 0, stream, ka);
+    if (a.bias || a.relu) {
+      BiasActArgs b{a.C, a.bias, a.M, a.N, a.ldc, a.relu};
+      long long total = (long long)a.M * a.N;
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      launch("bias_act", bias_act_kernel, dim3(blocks), dim3(256), 0, stream, b);
+    }
+  } else {
+    launch("gemm_f32", gemm_kernel, dim3(gx, gy, 1), dim3(256), 0, stream, ka);
+  }
+}
+
+}  // namespace dtf

@@ -1,0 +1,118 @@
+// Optimizer and flat-buffer kernels: one launch updates every parameter of the model.
+//
+// Parameters, gradients and optimizer slots each live in one contiguous fp32 arena, so the
+// "multi-tensor apply" is a single vectorised stream over n floats. The step-dependent scalars
+// (bias-corrected learning rate, gradient scale 1/sum(mask) that turns the all-reduced SUM into
+// the mean of the aggregated replicas) are read from a small device buffer so that a captured
+// hipGraph can be replayed with new values.
+#include "ops.h"
+
+namespace dtf {
+namespace {
+
+inline int flat_blocks(long long n4) {
+  long long b = (n4 + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(FlatOptArgs a) {
+  const float lr_t = a.hyper[0], b1 = a.hyper[1], b2 = a.hyper[2], eps = a.hyper[3], gs = a.hyper[4];
+  const long long n4 = a.n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  floatx4* p4 = reinterpret_cast<floatx4*>(a.p);
+  const floatx4* g4 = reinterpret_cast<const floatx4*>(a.g);
+  floatx4* m4 = reinterpret_cast<floatx4*>(a.m);
+  floatx4* v4 = reinterpret_cast<floatx4*>(a.v);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    floatx4 p = p4[i], m = m4[i], v = v4[i];
+    const floatx4 g = g4[i] * gs;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      m[e] = b1 * m[e] + (1.f - b1) * g[e];
+      v[e] = b2 * v[e] + (1.f - b2) * g[e] * g[e];
+      p[e] -= lr_t * m[e] / (sqrtf(v[e]) + eps);
+    }
+    p4[i] = p;
+    m4[i] = m;
+    v4[i] = v;
+  }
+  // tail (n not a multiple of 4)
+  const long long tail0 = n4 << 2;
+  const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi < a.n - tail0) {
+    const long long i = tail0 + gi;
+    const float g = a.g[i] * gs;
+    const float m = b1 * a.m[i] + (1.f - b1) * g;
+    const float v = b2 * a.v[i] + (1.f - b2) * g * g;
+    a.m[i] = m;
+    a.v[i] = v;
+    a.p[i] -= lr_t * m / (sqrtf(v) + eps);
+  }
+}
+
+__global__ __launch_bounds__(256) void momentum_kernel(FlatOptArgs a) {
+  const float lr = a.hyper[0], gs = a.hyper[4], mu = a.hyper[5], wd = a.hyper[6];
+  const long long n4 = a.n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  floatx4* p4 = reinterpret_cast<floatx4*>(a.p);
+  const floatx4* g4 = reinterpret_cast<const floatx4*>(a.g);
+  floatx4* m4 = reinterpret_cast<floatx4*>(a.m);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    floatx4 p = p4[i], m = m4[i];
+    const floatx4 g = g4[i] * gs + p * wd;
+    m = m * mu + g;
+    p -= m * lr;
+    p4[i] = p;
+    m4[i] = m;
+  }
+  const long long tail0 = n4 << 2;
+  const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi < a.n - tail0) {
+    const long long i = tail0 + gi;
+    const float g = a.g[i] * gs + wd * a.p[i];
+    const float m = mu * a.m[i] + g;
+    a.m[i] = m;
+    a.p[i] -= lr * m;
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(FlatScaleArgs a) {
+  const float s = a.scale_dev ? *a.scale_dev : a.scale;
+  const long long n4 = a.n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  floatx4* x4 = reinterpret_cast<floatx4*>(a.x);
+  const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long long i = gi; i < n4; i += stride) x4[i] = x4[i] * s;
+  const long long tail0 = n4 << 2;
+  if (gi < a.n - tail0) a.x[tail0 + gi] *= s;
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(AxpyArgs a) {
+  const long long n4 = a.n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  floatx4* y4 = reinterpret_cast<floatx4*>(a.y);
+  const floatx4* x4 = reinterpret_cast<const floatx4*>(a.x);
+  const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long long i = gi; i < n4; i += stride) y4[i] = y4[i] + x4[i] * a.alpha;
+  const long long tail0 = n4 << 2;
+  if (gi < a.n - tail0) a.y[tail0 + gi] += a.alpha * a.x[tail0 + gi];
+}
+
+}  // namespace
+
+void fused_adam(const FlatOptArgs& a, hipStream_t stream) {
+  launch("fused_adam", adam_kernel, dim3(flat_blocks(a.n >> 2)), dim3(256), 0, stream, a);
+}
+void fused_momentum_sgd(const FlatOptArgs& a, hipStream_t stream) {
+  launch("fused_momentum_sgd", momentum_kernel, dim3(flat_blocks(a.n >> 2)), dim3(256), 0, stream, a);
+}
+void flat_scale(const FlatScaleArgs& a, hipStream_t stream) {
+  launch("flat_scale", scale_kernel, dim3(flat_blocks(a.n >> 2)), dim3(256), 0, stream, a);
+}
+void flat_axpy(const AxpyArgs& a, hipStream_t stream) {
+  launch("flat_axpy", axpy_kernel, dim3(flat_blocks(a.n >> 2)), dim3(256), 0, stream, a);
+}
+
+}  // namespace dtf

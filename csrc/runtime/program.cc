@@ -1,0 +1,131 @@
+#include "program.h"
+
+#include <mutex>
+#include <unordered_map>
+
+namespace dtf {
+
+Program*& current_recorder() {
+  static thread_local Program* rec = nullptr;
+  return rec;
+}
+
+void ensure_dynamic_lds(const void* fn, size_t shmem) {
+  // Kernels asking for more than the default dynamic LDS window must raise the function's
+  // limit once. Remember the largest request per kernel.
+  if (shmem <= 48 * 1024) return;
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> seen;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = seen.find(fn);
+  if (it != seen.end() && it->second >= shmem) return;
+  DTF_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  seen[fn] = shmem;
+}
+
+void issue(const LaunchRecord& r, hipStream_t stream) {
+  switch (r.kind) {
+    case LaunchRecord::KERNEL: {
+      void* argv[1] = {const_cast<char*>(r.args.data())};
+      DTF_HIP_CHECK(hipLaunchKernel(r.fn, r.grid, r.block, argv, r.shmem, stream));
+      break;
+    }
+    case LaunchRecord::MEMSET:
+      DTF_HIP_CHECK(hipMemsetAsync(r.dst, r.value, r.bytes, stream));
+      break;
+    case LaunchRecord::MEMCPY:
+      DTF_HIP_CHECK(hipMemcpyAsync(r.dst, r.src, r.bytes, hipMemcpyDeviceToDevice, stream));
+      break;
+  }
+}
+
+void memset_async(void* dst, int value, size_t bytes, hipStream_t stream) {
+  LaunchRecord r;
+  r.kind = LaunchRecord::MEMSET;
+  r.name = "memset";
+  r.dst = dst;
+  r.value = value;
+  r.bytes = bytes;
+  if (Program* p = current_recorder())
+    p->records.push_back(std::move(r));
+  else
+    issue(r, stream);
+}
+
+void memcpy_async(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  LaunchRecord r;
+  r.kind = LaunchRecord::MEMCPY;
+  r.name = "memcpy";
+  r.dst = dst;
+  r.src = src;
+  r.bytes = bytes;
+  if (Program* p = current_recorder())
+    p->records.push_back(std::move(r));
+  else
+    issue(r, stream);
+}
+
+Program::~Program() {
+  for (auto& g : graphs_) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+  }
+}
+
+void Program::run(hipStream_t stream, int seg) const {
+  size_t b = 0, e = records.size();
+  if (seg >= 0) {
+    if ((size_t)seg >= seg_begin.size()) throw std::runtime_error("Program::run: bad segment");
+    b = seg_begin[seg];
+    e = ((size_t)seg + 1 < seg_begin.size()) ? seg_begin[seg + 1] : records.size();
+  }
+  for (size_t i = b; i < e; ++i) issue(records[i], stream);
+}
+
+void Program::instantiate(hipStream_t stream, int seg) {
+  size_t slot = (size_t)(seg + 1);
+  if (graphs_.size() <= slot) graphs_.resize(slot + 1);
+  GraphSlot& g = graphs_[slot];
+  if (g.exec) {
+    (void)hipGraphExecDestroy(g.exec);
+    g.exec = nullptr;
+  }
+  if (g.graph) {
+    (void)hipGraphDestroy(g.graph);
+    g.graph = nullptr;
+  }
+  // A capture must not run on the legacy default stream.
+  hipStream_t cap = stream;
+  bool own = false;
+  if (cap == nullptr) {
+    DTF_HIP_CHECK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+    own = true;
+  }
+  DTF_HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+  try {
+    run(cap, seg);
+  } catch (...) {
+    hipGraph_t tmp = nullptr;
+    (void)hipStreamEndCapture(cap, &tmp);
+    if (tmp) (void)hipGraphDestroy(tmp);
+    if (own) (void)hipStreamDestroy(cap);
+    throw;
+  }
+  DTF_HIP_CHECK(hipStreamEndCapture(cap, &g.graph));
+  DTF_HIP_CHECK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+  if (own) DTF_HIP_CHECK(hipStreamDestroy(cap));
+}
+
+bool Program::instantiated(int seg) const {
+  size_t slot = (size_t)(seg + 1);
+  return slot < graphs_.size() && graphs_[slot].exec != nullptr;
+}
+
+void Program::replay(hipStream_t stream, int seg) const {
+  size_t slot = (size_t)(seg + 1);
+  if (slot >= graphs_.size() || !graphs_[slot].exec)
+    throw std::runtime_error("Program::replay: segment not instantiated");
+  DTF_HIP_CHECK(hipGraphLaunch(graphs_[slot].exec, stream));
+}
+
+}  // namespace dtf

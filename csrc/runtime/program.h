@@ -1,0 +1,99 @@
+// Launch dispatcher and recorded step programs.
+//
+// Every kernel in csrc/kernels takes exactly one POD argument struct by value. Host launchers
+// call dtf::launch(); when a Program is recording on the calling thread the launch is appended
+// to that program instead of being issued, so a whole training step (forward, backward,
+// optimizer) becomes a flat list of launches that can be (a) replayed from C++ with no Python
+// in the loop, (b) split into segments with collectives issued between them, or (c) captured
+// once into a hipGraph and replayed with a single host call.
+//
+// This plays the role of the TensorFlow graph executor the reference relies on
+// (reference: DistributedLeNet/src/distributed_train.py:312 `sess.run([train_op, global_step])`).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace dtf {
+
+#define DTF_HIP_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess)                                                                \
+      throw std::runtime_error(std::string(#expr) + " failed: " + hipGetErrorString(_e)); \
+  } while (0)
+
+struct LaunchRecord {
+  enum Kind { KERNEL = 0, MEMSET = 1, MEMCPY = 2 } kind = KERNEL;
+  std::string name;
+  const void* fn = nullptr;
+  dim3 grid, block;
+  size_t shmem = 0;
+  std::vector<char> args;  // the kernel's POD argument struct
+  // memset / memcpy
+  void* dst = nullptr;
+  const void* src = nullptr;
+  int value = 0;
+  size_t bytes = 0;
+};
+
+class Program {
+ public:
+  ~Program();
+  std::vector<LaunchRecord> records;
+  // Segment boundaries: segment i covers records [seg_begin[i], seg_begin[i+1]).
+  std::vector<size_t> seg_begin{0};
+
+  void mark_segment() { seg_begin.push_back(records.size()); }
+  size_t num_segments() const { return seg_begin.size(); }
+  // Issue the launches of one segment (or all with seg < 0) on `stream`.
+  void run(hipStream_t stream, int seg = -1) const;
+  // Capture segment `seg` (or everything) into a hipGraph and keep the executable.
+  void instantiate(hipStream_t stream, int seg = -1);
+  // Replay a previously instantiated graph.
+  void replay(hipStream_t stream, int seg = -1) const;
+  bool instantiated(int seg = -1) const;
+
+ private:
+  struct GraphSlot {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+  };
+  // slot 0 = whole program, slot i+1 = segment i
+  std::vector<GraphSlot> graphs_;
+};
+
+// The program currently recording on this thread (nullptr = launch immediately).
+Program*& current_recorder();
+
+void ensure_dynamic_lds(const void* fn, size_t shmem);
+void issue(const LaunchRecord& r, hipStream_t stream);
+
+template <typename Args>
+inline void launch(const char* name, void (*kernel)(Args), dim3 grid, dim3 block, size_t shmem,
+                   hipStream_t stream, const Args& args) {
+  static_assert(std::is_trivially_copyable<Args>::value, "kernel args must be POD");
+  LaunchRecord r;
+  r.kind = LaunchRecord::KERNEL;
+  r.name = name;
+  r.fn = reinterpret_cast<const void*>(kernel);
+  r.grid = grid;
+  r.block = block;
+  r.shmem = shmem;
+  r.args.resize(sizeof(Args));
+  std::memcpy(r.args.data(), &args, sizeof(Args));
+  ensure_dynamic_lds(r.fn, shmem);
+  if (Program* p = current_recorder()) {
+    p->records.push_back(std::move(r));
+  } else {
+    issue(r, stream);
+  }
+}
+
+void memset_async(void* dst, int value, size_t bytes, hipStream_t stream);
+void memcpy_async(void* dst, const void* src, size_t bytes, hipStream_t stream);
+
+}  // namespace dtf

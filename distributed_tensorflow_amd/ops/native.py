@@ -1,0 +1,536 @@
+"""Tensor-level wrappers around the gfx950 HIP extension (`_hip`).
+
+The extension takes raw device addresses; this module checks shapes/dtypes/contiguity on the
+host before every launch (a kernel that faults can take the whole GPU host down), allocates
+outputs with torch, and passes the current torch stream so launches order with everything else
+torch does. When a GPU is present the extension is mandatory: failing to import it raises
+instead of silently falling back to PyTorch ops.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .reference import BN_EPSILON, same_pad
+
+try:  # the .so is built in-tree by build_native.py
+    from .. import _hip  # type: ignore
+except ImportError as exc:  # pragma: no cover - exercised only on broken installs
+    _hip = None
+    _import_error = exc
+else:
+    _import_error = None
+
+IN_RAW, IN_BNRELU = 0, 1
+RES_NONE, RES_IDENT, RES_BNRELU, RES_SHORTCUT_A = 0, 1, 2, 3
+EPI_PLAIN, EPI_BIAS_RELU, EPI_MASK, EPI_BIAS = 0, 1, 2, 3
+BWD_RES_NONE, BWD_RES_IDENT, BWD_RES_SHORTCUT_A = 0, 1, 2
+
+
+def available() -> bool:
+    return _hip is not None and torch.cuda.is_available()
+
+
+def require() -> None:
+    """Raises unless the HIP extension is importable and a GPU is visible."""
+    if _hip is None:
+        raise RuntimeError(
+            "distributed_tensorflow_amd._hip is not built (run `python build_native.py`): %r" % (_import_error,)
+        )
+    if not torch.cuda.is_available():
+        raise RuntimeError("no GPU visible to torch; the HIP ops need an MI355X")
+
+
+def hip():
+    if _hip is None:
+        raise RuntimeError("distributed_tensorflow_amd._hip is not built: %r" % (_import_error,))
+    return _hip
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a GPU tensor")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+    if t.data_ptr() % 16 != 0 and t.numel() > 0:
+        raise ValueError(f"{name}: storage must be 16-byte aligned")
+    return t.data_ptr()
+
+
+@dataclass
+class BnState:
+    """Batch statistics (fp64 sum / sum of squares) plus affine parameters of one BN layer."""
+
+    sums: torch.Tensor   # float64 [2*C]
+    gamma: torch.Tensor  # float32 [C]
+    beta: torch.Tensor   # float32 [C]
+    count: int           # B*H*W the statistics are taken over
+    eps: float = BN_EPSILON
+
+    def ref(self):
+        c = self.gamma.numel()
+        if self.sums.dtype != torch.float64 or self.sums.numel() != 2 * c:
+            raise ValueError("BnState.sums must be float64 [2*C]")
+        if self.beta.numel() != c:
+            raise ValueError("BnState gamma/beta size mismatch")
+        for t in (self.sums, self.gamma, self.beta):
+            if not t.is_cuda or not t.is_contiguous():
+                raise ValueError("BnState tensors must be contiguous GPU tensors")
+        return (self.sums.data_ptr(), self.gamma.data_ptr(), self.beta.data_ptr(), 1.0 / float(self.count), float(self.eps))
+
+    @property
+    def channels(self) -> int:
+        return self.gamma.numel()
+
+
+def pad_cin(c: int) -> int:
+    for p in (4, 16, 32, 64):
+        if c <= p:
+            return p
+    raise ValueError("convolutions with more than 64 input channels are not supported")
+
+
+def packed_floats(ks: int, cin: int, cout: int, flip: bool) -> int:
+    return hip().packed_weight_floats(ks, cin, cout, int(flip))
+
+
+def pack_weights(w: torch.Tensor, flip: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """HWIO filter -> MFMA B-operand order; flip=True packs the data-gradient filter."""
+    require()
+    ks, ks2, cin, cout = w.shape
+    if ks != ks2:
+        raise ValueError("square filters only")
+    n = packed_floats(ks, cin, cout, flip)
+    if out is None:
+        out = torch.empty(n, device=w.device, dtype=torch.float32)
+    if out.numel() != n:
+        raise ValueError("pack_weights: wrong output size")
+    hip().pack_conv_weights(_chk(w, "w"), _chk(out, "out"), ks, cin, cout, int(flip), stream())
+    return out
+
+
+def conv_fprop(
+    x: torch.Tensor,
+    wpk: torch.Tensor,
+    *,
+    ks: int,
+    cout: int,
+    stride: int = 1,
+    upsample: bool = False,
+    pad: Optional[int] = None,
+    out_hw: Optional[tuple[int, int]] = None,
+    in_bn: Optional[BnState] = None,
+    res_mode: int = RES_NONE,
+    res: Optional[torch.Tensor] = None,
+    res_bn: Optional[BnState] = None,
+    epi_mode: int = EPI_PLAIN,
+    bias: Optional[torch.Tensor] = None,
+    mask_src: Optional[torch.Tensor] = None,
+    mask_bn: Optional[BnState] = None,
+    extra: Optional[torch.Tensor] = None,
+    out_sums: Optional[torch.Tensor] = None,
+    out: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """Forward-shaped convolution with fused prologue/epilogues (see csrc/kernels/conv.h)."""
+    require()
+    b, h, w_, cin = x.shape
+    if upsample:
+        if stride != 1:
+            raise ValueError("upsample implies an output stride of 1")
+        if out_hw is None:
+            out_hw = (2 * h, 2 * w_)
+        if pad is None:
+            raise ValueError("upsample needs an explicit pad")
+    if out_hw is None:
+        ho, pb, _ = same_pad(h, ks, stride)
+        wo, pbw, _ = same_pad(w_, ks, stride)
+        if pad is None:
+            if pb != pbw:
+                raise ValueError("non-square SAME padding is not supported")
+            pad = pb
+    else:
+        ho, wo = out_hw
+        if pad is None:
+            raise ValueError("out_hw needs an explicit pad")
+    # packed filter must match (ks, cin, cout)
+    cp = pad_cin(cin)
+    kg = ks * ks * (cp // 16) if cp >= 16 else (ks * ks + 3) // 4
+    nt_total = (cout + 15) // 16
+    if wpk.numel() != kg * nt_total * 256:
+        raise ValueError(f"packed filter has {wpk.numel()} floats, expected {kg * nt_total * 256}")
+    if out is None:
+        out = torch.empty((b, ho, wo, cout), device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != (b, ho, wo, cout):
+        raise ValueError("conv_fprop: out has the wrong shape")
+    d = dict(
+        B=b, H=h, W=w_, Cin=cin, Ho=ho, Wo=wo, Cout=cout, pad=pad, stride=stride, upsample=int(upsample),
+        nt_total=nt_total, in_mode=IN_RAW, res_mode=res_mode, epi_mode=epi_mode,
+    )
+    d["in"] = _chk(x, "x")
+    d["wpk"] = _chk(wpk, "wpk")
+    d["out"] = _chk(out, "out")
+    if in_bn is not None:
+        if in_bn.channels != cin:
+            raise ValueError("in_bn channel mismatch")
+        d["in_mode"] = IN_BNRELU
+        d["in_bn"] = in_bn.ref()
+    if res_mode in (RES_IDENT, RES_BNRELU):
+        if res is None or tuple(res.shape) != (b, ho, wo, cout):
+            raise ValueError("residual must match the output shape")
+        d["res"] = _chk(res, "res")
+        if res_mode == RES_BNRELU:
+            if res_bn is None or res_bn.channels != cout:
+                raise ValueError("res_bn missing or channel mismatch")
+            d["res_bn"] = res_bn.ref()
+    elif res_mode == RES_SHORTCUT_A:
+        if res is None or tuple(res.shape) != (b, 2 * ho, 2 * wo, cout // 2) or cout % 4:
+            raise ValueError("option-A shortcut source must be [B,2Ho,2Wo,Cout/2]")
+        d["res"] = _chk(res, "res")
+    if epi_mode in (EPI_BIAS_RELU, EPI_BIAS):
+        if bias is None or bias.numel() != cout:
+            raise ValueError("bias missing or wrong size")
+        d["bias"] = _chk(bias, "bias")
+    elif epi_mode == EPI_MASK:
+        if mask_src is None or tuple(mask_src.shape) != (b, ho, wo, cout) or mask_bn is None or mask_bn.channels != cout:
+            raise ValueError("EPI_MASK needs mask_src of the output shape and mask_bn")
+        d["mask_src"] = _chk(mask_src, "mask_src")
+        d["mask_bn"] = mask_bn.ref()
+        if extra is not None:
+            if tuple(extra.shape) != (b, ho, wo, cout):
+                raise ValueError("extra must match the output shape")
+            d["extra"] = _chk(extra, "extra")
+    if out_sums is not None:
+        if out_sums.numel() != 2 * cout:
+            raise ValueError("out_sums must be [2*Cout]")
+        d["out_sums"] = _chk(out_sums, "out_sums", torch.float64)
+    hip().conv_fprop(d, ks, stream())
+    return out
+
+
+def conv_wgrad(
+    x: torch.Tensor,
+    dout: torch.Tensor,
+    dw: torch.Tensor,
+    *,
+    stride: int = 1,
+    in_bn: Optional[BnState] = None,
+    tiles_per_block: int = 0,
+) -> torch.Tensor:
+    """dw (HWIO, pre-zeroed or holding a running sum) += filter gradient."""
+    require()
+    b, h, w_, cin = x.shape
+    ks, _, cin2, cout = dw.shape
+    b2, ho, wo, cout2 = dout.shape
+    eho, pb, _ = same_pad(h, ks, stride)
+    ewo, _, _ = same_pad(w_, ks, stride)
+    if (b2, ho, wo, cout2, cin2) != (b, eho, ewo, cout, cin):
+        raise ValueError("conv_wgrad: shape mismatch")
+    d = dict(B=b, H=h, W=w_, Cin=cin, Ho=ho, Wo=wo, Cout=cout, pad=pb, stride=stride, in_mode=IN_RAW,
+             tiles_per_block=tiles_per_block)
+    d["in"] = _chk(x, "x")
+    d["dout"] = _chk(dout, "dout")
+    d["dw"] = _chk(dw, "dw")
+    if in_bn is not None:
+        if in_bn.channels != cin:
+            raise ValueError("in_bn channel mismatch")
+        d["in_mode"] = IN_BNRELU
+        d["in_bn"] = in_bn.ref()
+    hip().conv_wgrad(d, ks, stream())
+    return dw
+
+
+# ----------------------------------------------------------------------------- batch norm
+def bn_stats(x: torch.Tensor, sums: Optional[torch.Tensor] = None) -> torch.Tensor:
+    require()
+    c = x.shape[-1]
+    if sums is None:
+        sums = torch.zeros(2 * c, device=x.device, dtype=torch.float64)
+    hip().bn_stats(dict(x=_chk(x, "x"), sums=_chk(sums, "sums", torch.float64), n_rows=x.numel() // c, C=c), stream())
+    return sums
+
+
+def bn_apply(x: torch.Tensor, bn: BnState, relu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    require()
+    c = x.shape[-1]
+    if bn.channels != c:
+        raise ValueError("bn channel mismatch")
+    if out is None:
+        out = torch.empty_like(x)
+    hip().bn_apply(dict(x=_chk(x, "x"), y=_chk(out, "out"), bn=bn.ref(), n_rows=x.numel() // c, C=c, relu=int(relu)), stream())
+    return out
+
+
+def bn_relu_bwd_reduce(dy, x, bn: BnState, gsums, relu=True, out=None):
+    require()
+    c = x.shape[-1]
+    if dy.shape != x.shape or bn.channels != c or gsums.numel() != 2 * c:
+        raise ValueError("bn_relu_bwd_reduce: shape mismatch")
+    if out is None:
+        out = torch.empty_like(dy)
+    hip().bn_relu_bwd_reduce(
+        dict(dy=_chk(dy, "dy"), x=_chk(x, "x"), g=_chk(out, "g"), bn=bn.ref(), gsums=_chk(gsums, "gsums", torch.float64),
+             n_rows=x.numel() // c, C=c, relu=int(relu)), stream())
+    return out
+
+
+def bn_bwd_apply(g, x, bn: BnState, gsums, *, dgamma=None, dbeta=None, res_mode=BWD_RES_NONE, res=None, out=None):
+    require()
+    c = x.shape[-1]
+    if g.shape != x.shape or bn.channels != c or gsums.numel() != 2 * c:
+        raise ValueError("bn_bwd_apply: shape mismatch")
+    if out is None:
+        out = torch.empty_like(g)
+    d = dict(g=_chk(g, "g"), x=_chk(x, "x"), dx=_chk(out, "dx"), bn=bn.ref(), gsums=_chk(gsums, "gsums", torch.float64),
+             n_rows=x.numel() // c, C=c, res_mode=res_mode)
+    if dgamma is not None:
+        if dgamma.numel() != c or dbeta is None or dbeta.numel() != c:
+            raise ValueError("dgamma/dbeta size mismatch")
+        d["dgamma"] = _chk(dgamma, "dgamma")
+        d["dbeta"] = _chk(dbeta, "dbeta")
+    if res_mode == BWD_RES_IDENT:
+        if res is None or res.shape != x.shape:
+            raise ValueError("identity residual gradient must match x")
+        d["res"] = _chk(res, "res")
+    elif res_mode == BWD_RES_SHORTCUT_A:
+        b, h, w_, _ = x.shape
+        if res is None or tuple(res.shape) != (b, h // 2, w_ // 2, 2 * c) or h % 2 or w_ % 2:
+            raise ValueError("shortcut-A residual gradient must be [B,H/2,W/2,2C]")
+        d["res"] = _chk(res, "res")
+        d["H"], d["W"] = h, w_
+    hip().bn_bwd_apply(d, stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- head / loss
+def head_fwd(x, bn: BnState, fc_w, fc_b, labels, feat, logits, dlogits, loss, correct=None):
+    require()
+    b, h, w_, c = x.shape
+    k = fc_w.shape[1]
+    if tuple(fc_w.shape) != (c, k) or fc_b.numel() != k or labels.numel() != b or bn.channels != c:
+        raise ValueError("head_fwd: shape mismatch")
+    if tuple(feat.shape) != (b, c) or tuple(logits.shape) != (b, k) or tuple(dlogits.shape) != (b, k):
+        raise ValueError("head_fwd: output shape mismatch")
+    d = dict(x=_chk(x, "x"), bn=bn.ref(), fc_w=_chk(fc_w, "fc_w"), fc_b=_chk(fc_b, "fc_b"),
+             labels=_chk(labels, "labels", torch.int32), feat=_chk(feat, "feat"), logits=_chk(logits, "logits"),
+             dlogits=_chk(dlogits, "dlogits"), loss=_chk(loss, "loss"), B=b, HW=h * w_, C=c, K=k)
+    if correct is not None:
+        d["correct"] = _chk(correct, "correct", torch.int32)
+    hip().head_fwd(d, stream())
+
+
+def head_bwd(x, bn: BnState, fc_w, feat, dlogits, g, gsums, d_fc_w, d_fc_b):
+    require()
+    b, h, w_, c = x.shape
+    k = fc_w.shape[1]
+    if g.shape != x.shape or tuple(d_fc_w.shape) != (c, k) or d_fc_b.numel() != k or gsums.numel() != 2 * c:
+        raise ValueError("head_bwd: shape mismatch")
+    if tuple(feat.shape) != (b, c) or tuple(dlogits.shape) != (b, k):
+        raise ValueError("head_bwd: saved tensor shape mismatch")
+    hip().head_bwd(
+        dict(x=_chk(x, "x"), bn=bn.ref(), fc_w=_chk(fc_w, "fc_w"), feat=_chk(feat, "feat"), dlogits=_chk(dlogits, "dlogits"),
+             g=_chk(g, "g"), gsums=_chk(gsums, "gsums", torch.float64), d_fc_w=_chk(d_fc_w, "d_fc_w"),
+             d_fc_b=_chk(d_fc_b, "d_fc_b"), B=b, HW=h * w_, C=c, K=k), stream())
+
+
+def softmax_xent(logits, labels, loss, dlogits=None, correct=None):
+    require()
+    b, k = logits.shape
+    if labels.numel() != b:
+        raise ValueError("softmax_xent: label count mismatch")
+    d = dict(logits=_chk(logits, "logits"), labels=_chk(labels, "labels", torch.int32), loss=_chk(loss, "loss"), B=b, K=k)
+    if dlogits is not None:
+        if dlogits.shape != logits.shape:
+            raise ValueError("dlogits shape mismatch")
+        d["dlogits"] = _chk(dlogits, "dlogits")
+    if correct is not None:
+        d["correct"] = _chk(correct, "correct", torch.int32)
+    hip().softmax_xent(d, stream())
+
+
+def top1_count(logits, labels, correct):
+    require()
+    b, k = logits.shape
+    hip().top1_count(dict(logits=_chk(logits, "logits"), labels=_chk(labels, "labels", torch.int32),
+                          correct=_chk(correct, "correct", torch.int32), B=b, K=k), stream())
+
+
+# ----------------------------------------------------------------------------- optimizers / flat
+HYPER_SLOTS = 8  # lr_t, beta1, beta2, eps, grad_scale, momentum, weight_decay, spare
+
+
+def fused_adam(p, g, m, v, hyper):
+    require()
+    n = p.numel()
+    if g.numel() != n or m.numel() != n or v.numel() != n or hyper.numel() < HYPER_SLOTS:
+        raise ValueError("fused_adam: size mismatch")
+    hip().fused_adam(dict(p=_chk(p, "p"), g=_chk(g, "g"), m=_chk(m, "m"), v=_chk(v, "v"), hyper=_chk(hyper, "hyper"), n=n), stream())
+
+
+def fused_momentum_sgd(p, g, m, hyper):
+    require()
+    n = p.numel()
+    if g.numel() != n or m.numel() != n or hyper.numel() < HYPER_SLOTS:
+        raise ValueError("fused_momentum_sgd: size mismatch")
+    hip().fused_momentum_sgd(dict(p=_chk(p, "p"), g=_chk(g, "g"), m=_chk(m, "m"), hyper=_chk(hyper, "hyper"), n=n), stream())
+
+
+def flat_scale(x, scale: float = 1.0, scale_dev: Optional[torch.Tensor] = None):
+    require()
+    d = dict(x=_chk(x, "x"), scale=float(scale), n=x.numel())
+    if scale_dev is not None:
+        d["scale_dev"] = _chk(scale_dev, "scale_dev")
+    hip().flat_scale(d, stream())
+    return x
+
+
+def flat_axpy(y, x, alpha: float):
+    require()
+    if x.numel() != y.numel():
+        raise ValueError("flat_axpy: size mismatch")
+    hip().flat_axpy(dict(y=_chk(y, "y"), x=_chk(x, "x"), alpha=float(alpha), n=y.numel()), stream())
+    return y
+
+
+def memset_zero(t: torch.Tensor):
+    require()
+    hip().memset(t.data_ptr(), 0, t.numel() * t.element_size(), stream())
+
+
+# ----------------------------------------------------------------------------- elementwise & friends
+def add_relu_fwd(a, b, relu_first: bool, out=None):
+    require()
+    if a.shape != b.shape:
+        raise ValueError("add_relu: shape mismatch")
+    if out is None:
+        out = torch.empty_like(a)
+    hip().add_relu_fwd(dict(a=_chk(a, "a"), b=_chk(b, "b"), out=_chk(out, "out"), n=a.numel(), relu_first=int(relu_first)), stream())
+    return out
+
+
+def add_relu_bwd(dout, a, b, relu_first: bool):
+    require()
+    da, db = torch.empty_like(a), torch.empty_like(b)
+    hip().add_relu_bwd(dict(dout=_chk(dout, "dout"), a=_chk(a, "a"), b=_chk(b, "b"), da=_chk(da, "da"), db=_chk(db, "db"),
+                            n=a.numel(), relu_first=int(relu_first)), stream())
+    return da, db
+
+
+def relu_bwd(dy, y, out=None):
+    require()
+    if out is None:
+        out = torch.empty_like(dy)
+    hip().relu_bwd(dict(dy=_chk(dy, "dy"), y=_chk(y, "y"), dx=_chk(out, "dx"), n=dy.numel()), stream())
+    return out
+
+
+def shortcut_a_fwd(x):
+    require()
+    b, h, w_, c = x.shape
+    if h % 2 or w_ % 2 or c % 2:
+        raise ValueError("shortcut_a: even H, W, C required")
+    y = torch.empty((b, h // 2, w_ // 2, 2 * c), device=x.device, dtype=torch.float32)
+    hip().shortcut_a_fwd(dict(x=_chk(x, "x"), y=_chk(y, "y"), B=b, H=h, W=w_, C=c), stream())
+    return y
+
+
+def shortcut_a_bwd(dy, x_shape, out=None, accumulate=False):
+    require()
+    b, h, w_, c = x_shape
+    if tuple(dy.shape) != (b, h // 2, w_ // 2, 2 * c):
+        raise ValueError("shortcut_a_bwd: shape mismatch")
+    if out is None:
+        out = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+    hip().shortcut_a_bwd(dict(dy=_chk(dy, "dy"), dx=_chk(out, "dx"), B=b, H=h, W=w_, C=c, accumulate=int(accumulate)), stream())
+    return out
+
+
+def maxpool2x2_fwd(x):
+    require()
+    b, h, w_, c = x.shape
+    y = torch.empty((b, (h + 1) // 2, (w_ + 1) // 2, c), device=x.device, dtype=torch.float32)
+    arg = torch.empty(y.shape, device=x.device, dtype=torch.uint8)
+    hip().maxpool2x2_fwd(dict(x=_chk(x, "x"), y=_chk(y, "y"), argmax=arg.data_ptr(), B=b, H=h, W=w_, C=c), stream())
+    return y, arg
+
+
+def maxpool2x2_bwd(dy, arg, y, x_shape, relu_mask: bool = False):
+    require()
+    b, h, w_, c = x_shape
+    if dy.shape != y.shape or arg.shape != y.shape:
+        raise ValueError("maxpool2x2_bwd: shape mismatch")
+    dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+    hip().maxpool2x2_bwd(dict(dy=_chk(dy, "dy"), argmax=arg.data_ptr(), y=_chk(y, "y"), dx=_chk(dx, "dx"),
+                              B=b, H=h, W=w_, C=c, relu_mask=int(relu_mask)), stream())
+    return dx
+
+
+def dropout(x, keep_prob: float, seed: int, offset: int, out=None):
+    require()
+    if out is None:
+        out = torch.empty_like(x)
+    hip().dropout(dict(x=_chk(x, "x"), y=_chk(out, "y"), n=x.numel(), keep_prob=float(keep_prob), seed=int(seed), offset=int(offset)), stream())
+    return out
+
+
+def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, relu=False, out=None, accumulate=False):
+    """C = op(A) @ op(B) (+bias)(relu) with row-major 2-D tensors."""
+    require()
+    if a.dim() != 2 or b.dim() != 2:
+        raise ValueError("gemm: 2-D operands only")
+    m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    kb, n = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    if k != kb:
+        raise ValueError("gemm: inner dimensions differ")
+    if out is None:
+        out = torch.empty((m, n), device=a.device, dtype=torch.float32)
+    elif tuple(out.shape) != (m, n):
+        raise ValueError("gemm: out has the wrong shape")
+    d = dict(A=_chk(a, "A"), B=_chk(b, "B"), C=_chk(out, "C"), M=m, N=n, K=k, lda=a.shape[1], ldb=b.shape[1], ldc=n,
+             trans_a=int(trans_a), trans_b=int(trans_b), relu=int(relu), accumulate=int(accumulate))
+    if bias is not None:
+        if bias.numel() != n:
+            raise ValueError("gemm: bias size mismatch")
+        d["bias"] = _chk(bias, "bias")
+    hip().gemm_f32(d, stream())
+    return out
+
+
+def col_sum(x2d, out):
+    require()
+    n_rows, c = x2d.shape
+    if out.numel() != c:
+        raise ValueError("col_sum: size mismatch")
+    hip().col_sum(dict(x=_chk(x2d, "x"), out=_chk(out, "out"), n_rows=n_rows, C=c), stream())
+    return out
+
+
+def zero_fraction(x) -> float:
+    require()
+    z = torch.zeros(1, device=x.device, dtype=torch.int64)
+    hip().zero_count(dict(x=_chk(x, "x"), zeros=z.data_ptr(), n=x.numel()), stream())
+    return float(z.item()) / max(1, x.numel())
+
+
+def crop_whiten(src, index=None, offs=None, out_hw=None, whiten=True):
+    require()
+    n, hp, wp, c = src.shape
+    h, w_ = out_hw if out_hw is not None else (hp, wp)
+    b = index.numel() if index is not None else n
+    out = torch.empty((b, h, w_, c), device=src.device, dtype=torch.float32)
+    d = dict(src=_chk(src, "src"), out=_chk(out, "out"), B=b, HP=hp, WP=wp, H=h, W=w_, C=c, whiten=int(whiten))
+    if index is not None:
+        d["index"] = _chk(index, "index", torch.int32)
+    if offs is not None:
+        if offs.numel() != 2 * b:
+            raise ValueError("crop offsets must be [B,2]")
+        d["offs"] = _chk(offs, "offs", torch.int32)
+    hip().crop_whiten(d, stream())
+    return out

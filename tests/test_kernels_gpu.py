@@ -1,0 +1,387 @@
+"""Numerics of every HIP kernel against the plain PyTorch fp32/fp64 reference of the same op.
+
+Operands are asymmetric random tensors (a swapped row/column map in an MFMA epilogue passes on
+symmetric data), shapes include non-multiples of the tile sizes, and every test runs the
+native extension (native.require() raises if it is missing).
+"""
+import math
+
+import pytest
+import torch
+
+from distributed_tensorflow_amd.ops import native as nv
+from distributed_tensorflow_amd.ops import reference as ref
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rnd(*shape, scale=1.0, seed=None):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed if seed is not None else (hash(shape) & 0xFFFF) + 1)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def close(a, b, tol=2e-4):
+    a, b = a.double().cpu(), b.double().cpu()
+    denom = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item() / denom
+    assert err < tol, f"relative max error {err:.3e} (tol {tol})"
+
+
+def bn_state_for(x, gamma, beta):
+    c = x.shape[-1]
+    flat = x.reshape(-1, c).double()
+    sums = torch.cat([flat.sum(0), (flat * flat).sum(0)]).to(DEV)
+    return nv.BnState(sums, gamma, beta, flat.shape[0])
+
+
+CONV_CASES = [
+    # (B, H, W, Cin, Cout, ks, stride)
+    (3, 32, 32, 3, 16, 3, 1),
+    (3, 32, 32, 16, 16, 3, 1),
+    (3, 32, 32, 16, 32, 3, 2),
+    (3, 16, 16, 32, 32, 3, 1),
+    (3, 16, 16, 32, 64, 3, 2),
+    (5, 8, 8, 64, 64, 3, 1),
+    (2, 28, 28, 1, 32, 5, 1),
+    (2, 14, 14, 32, 64, 5, 1),
+    (2, 12, 20, 16, 16, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fprop_plain(case):
+    b, h, w, cin, cout, ks, s = case
+    x = rnd(b, h, w, cin)
+    wt = rnd(ks, ks, cin, cout, scale=0.1)
+    want = ref.conv2d_same(x, wt, s)
+    got = nv.conv_fprop(x, nv.pack_weights(wt), ks=ks, cout=cout, stride=s)
+    close(got, want)
+
+
+@pytest.mark.parametrize("case", CONV_CASES[1:6])
+def test_conv_fprop_bn_prologue_and_stats(case):
+    b, h, w, cin, cout, ks, s = case
+    x = rnd(b, h, w, cin, scale=2.0) + 0.3
+    gamma = rnd(cin).abs() + 0.5
+    beta = rnd(cin, scale=0.2)
+    wt = rnd(ks, ks, cin, cout, scale=0.1)
+    a = torch.relu(ref.batch_norm(x, gamma, beta))
+    want = ref.conv2d_same(a, wt, s)
+    sums = torch.zeros(2 * cout, device=DEV, dtype=torch.float64)
+    got = nv.conv_fprop(x, nv.pack_weights(wt), ks=ks, cout=cout, stride=s, in_bn=bn_state_for(x, gamma, beta), out_sums=sums)
+    close(got, want)
+    flat = want.reshape(-1, cout).double()
+    close(sums[:cout], flat.sum(0), 1e-5)
+    close(sums[cout:], (flat * flat).sum(0), 1e-5)
+
+
+def test_conv_fprop_residual_modes():
+    b, h, w, c = 4, 16, 16, 32
+    x = rnd(b, h, w, c)
+    wt = rnd(3, 3, c, c, scale=0.1)
+    res = rnd(b, h, w, c, seed=7)
+    base = ref.conv2d_same(x, wt, 1)
+    wpk = nv.pack_weights(wt)
+    close(nv.conv_fprop(x, wpk, ks=3, cout=c, res_mode=nv.RES_IDENT, res=res), base + res)
+    gamma, beta = rnd(c).abs() + 0.5, rnd(c, scale=0.3)
+    want = base + torch.relu(ref.batch_norm(res, gamma, beta))
+    close(nv.conv_fprop(x, wpk, ks=3, cout=c, res_mode=nv.RES_BNRELU, res=res, res_bn=bn_state_for(res, gamma, beta)), want)
+    # option-A shortcut: source at twice the resolution with half the channels
+    src = rnd(b, 2 * h, 2 * w, c // 2, seed=9)
+    want = base + ref.shortcut_a(src)
+    close(nv.conv_fprop(x, wpk, ks=3, cout=c, res_mode=nv.RES_SHORTCUT_A, res=src), want)
+
+
+def test_conv_fprop_bias_relu():
+    x = rnd(2, 14, 14, 32)
+    wt = rnd(5, 5, 32, 64, scale=0.05)
+    bias = rnd(64, scale=0.2)
+    want = torch.relu(ref.conv2d_same(x, wt, 1) + bias)
+    close(nv.conv_fprop(x, nv.pack_weights(wt), ks=5, cout=64, epi_mode=nv.EPI_BIAS_RELU, bias=bias), want)
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[3] >= 16])
+def test_conv_dgrad(case):
+    b, h, w, cin, cout, ks, s = case
+    x = rnd(b, h, w, cin).requires_grad_(True)
+    wt = rnd(ks, ks, cin, cout, scale=0.1)
+    y = ref.conv2d_same(x, wt, s)
+    dy = rnd(*y.shape, seed=11)
+    (want,) = torch.autograd.grad(y, x, dy)
+    _, pb, _ = ref.same_pad(h, ks, s)
+    wpk_t = nv.pack_weights(wt, flip=True)
+    got = nv.conv_fprop(dy, wpk_t, ks=ks, cout=cin, stride=1, upsample=(s == 2), pad=ks - 1 - pb, out_hw=(h, w))
+    close(got, want)
+
+
+def test_conv_dgrad_mask_epilogue():
+    b, h, w, cin, cout = 4, 16, 16, 32, 32
+    x_pre = rnd(b, h, w, cin, scale=1.5)          # BN input of the layer below
+    gamma, beta = rnd(cin).abs() + 0.5, rnd(cin, scale=0.3)
+    wt = rnd(3, 3, cin, cout, scale=0.1)
+    dy = rnd(b, h, w, cout, seed=3)
+    extra = rnd(b, h, w, cin, seed=5)
+    a = torch.relu(ref.batch_norm(x_pre, gamma, beta)).requires_grad_(True)
+    y = ref.conv2d_same(a, wt, 1)
+    (da,) = torch.autograd.grad(y, a, dy)
+    bnv = ref.batch_norm(x_pre, gamma, beta)
+    want = torch.where(bnv > 0, da + extra, torch.zeros_like(da))
+    st = bn_state_for(x_pre, gamma, beta)
+    gs = torch.zeros(2 * cin, device=DEV, dtype=torch.float64)
+    got = nv.conv_fprop(dy, nv.pack_weights(wt, flip=True), ks=3, cout=cin, pad=1, out_hw=(h, w),
+                        epi_mode=nv.EPI_MASK, mask_src=x_pre, mask_bn=st, extra=extra, out_sums=gs)
+    close(got, want)
+    mean, var = ref.batch_moments(x_pre)
+    xhat = (x_pre - mean) * torch.rsqrt(var + ref.BN_EPSILON)
+    close(gs[:cin], want.reshape(-1, cin).double().sum(0), 1e-4)
+    close(gs[cin:], (want * xhat).reshape(-1, cin).double().sum(0), 1e-4)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_wgrad(case):
+    b, h, w, cin, cout, ks, s = case
+    x = rnd(b, h, w, cin)
+    wt = rnd(ks, ks, cin, cout, scale=0.1).requires_grad_(True)
+    y = ref.conv2d_same(x, wt, s)
+    dy = rnd(*y.shape, seed=13)
+    (want,) = torch.autograd.grad(y, wt, dy)
+    dw = torch.zeros(want.shape, device=DEV)
+    nv.conv_wgrad(x, dy, dw, stride=s)
+    close(dw, want)
+    # several tiles per block exercises the persistent accumulation
+    dw2 = torch.zeros(want.shape, device=DEV)
+    nv.conv_wgrad(x, dy, dw2, stride=s, tiles_per_block=3)
+    close(dw2, want)
+
+
+def test_conv_wgrad_bn_prologue():
+    b, h, w, cin, cout = 4, 16, 16, 32, 32
+    x = rnd(b, h, w, cin, scale=1.5) + 0.2
+    gamma, beta = rnd(cin).abs() + 0.5, rnd(cin, scale=0.3)
+    a = torch.relu(ref.batch_norm(x, gamma, beta))
+    wt = rnd(3, 3, cin, cout, scale=0.1).requires_grad_(True)
+    y = ref.conv2d_same(a, wt, 1)
+    dy = rnd(*y.shape, seed=17)
+    (want,) = torch.autograd.grad(y, wt, dy)
+    dw = torch.zeros(want.shape, device=DEV)
+    nv.conv_wgrad(x, dy, dw, stride=1, in_bn=bn_state_for(x, gamma, beta))
+    close(dw, want)
+
+
+def test_bn_stats_apply_and_backward():
+    x = rnd(6, 16, 16, 32, scale=2.0) + 0.5
+    c = 32
+    gamma, beta = rnd(c).abs() + 0.5, rnd(c, scale=0.3)
+    sums = nv.bn_stats(x)
+    flat = x.reshape(-1, c).double()
+    close(sums[:c], flat.sum(0), 1e-6)
+    close(sums[c:], (flat * flat).sum(0), 1e-6)
+    st = nv.BnState(sums, gamma, beta, flat.shape[0])
+    close(nv.bn_apply(x, st, relu=True), torch.relu(ref.batch_norm(x, gamma, beta)))
+    close(nv.bn_apply(x, st, relu=False), ref.batch_norm(x, gamma, beta))
+
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = torch.relu(ref.batch_norm(xr, gr, br))
+    dy = rnd(*x.shape, seed=23)
+    dx_want, dg_want, db_want = torch.autograd.grad(y, (xr, gr, br), dy)
+    gs = torch.zeros(2 * c, device=DEV, dtype=torch.float64)
+    g = nv.bn_relu_bwd_reduce(dy, x, st, gs, relu=True)
+    dgamma, dbeta = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    res = rnd(*x.shape, seed=29)
+    dx = nv.bn_bwd_apply(g, x, st, gs, dgamma=dgamma, dbeta=dbeta, res_mode=nv.BWD_RES_IDENT, res=res)
+    close(dx, dx_want + res, 5e-4)
+    close(dgamma, dg_want, 5e-4)
+    close(dbeta, db_want, 5e-4)
+
+
+def test_bn_bwd_apply_shortcut_a():
+    b, h, w, c = 3, 16, 16, 16
+    x = rnd(b, h, w, c)
+    gamma, beta = rnd(c).abs() + 0.5, rnd(c, scale=0.3)
+    st = bn_state_for(x, gamma, beta)
+    dy_block = rnd(b, h // 2, w // 2, 2 * c, seed=31)
+    xs = x.clone().requires_grad_(True)
+    (want_sc,) = torch.autograd.grad(ref.shortcut_a(xs), xs, dy_block)
+    gs = torch.zeros(2 * c, device=DEV, dtype=torch.float64)
+    g = nv.bn_relu_bwd_reduce(torch.zeros_like(x), x, st, gs)
+    dx = nv.bn_bwd_apply(g, x, st, gs, res_mode=nv.BWD_RES_SHORTCUT_A, res=dy_block)
+    close(dx, want_sc)
+    close(nv.shortcut_a_fwd(x), ref.shortcut_a(x))
+    close(nv.shortcut_a_bwd(dy_block, tuple(x.shape)), want_sc)
+
+
+def test_head_fwd_bwd():
+    b, hw, c, k = 9, 8, 64, 10
+    x = rnd(b, hw, hw, c, scale=1.5)
+    gamma, beta = rnd(c).abs() + 0.5, rnd(c, scale=0.3)
+    fc_w, fc_b = rnd(c, k, scale=0.2), rnd(k, scale=0.1)
+    labels = torch.randint(0, k, (b,), device=DEV, dtype=torch.int32)
+    xr = x.clone().requires_grad_(True)
+    wr, br_ = fc_w.clone().requires_grad_(True), fc_b.clone().requires_grad_(True)
+    gr, be = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    feat_ref = torch.relu(ref.batch_norm(xr, gr, be)).mean(dim=(1, 2))
+    logits_ref = feat_ref @ wr + br_
+    loss_ref = ref.softmax_xent_mean(logits_ref, labels)
+    dx_w, dw_w, db_w, dg_w, dbe_w = torch.autograd.grad(loss_ref, (xr, wr, br_, gr, be))
+
+    st = bn_state_for(x, gamma, beta)
+    feat = torch.empty(b, c, device=DEV)
+    logits = torch.empty(b, k, device=DEV)
+    dlogits = torch.empty(b, k, device=DEV)
+    loss = torch.zeros(1, device=DEV)
+    correct = torch.zeros(1, device=DEV, dtype=torch.int32)
+    nv.head_fwd(x, st, fc_w, fc_b, labels, feat, logits, dlogits, loss, correct)
+    close(logits, logits_ref)
+    close(loss, loss_ref.reshape(1))
+    assert int(correct.item()) == ref.top1_hits(logits_ref, labels)
+
+    g = torch.empty_like(x)
+    gs = torch.zeros(2 * c, device=DEV, dtype=torch.float64)
+    d_w, d_b = torch.zeros_like(fc_w), torch.zeros_like(fc_b)
+    nv.head_bwd(x, st, fc_w, feat, dlogits, g, gs, d_w, d_b)
+    dgamma, dbeta = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    dx = nv.bn_bwd_apply(g, x, st, gs, dgamma=dgamma, dbeta=dbeta)
+    close(dx, dx_w, 5e-4)
+    close(d_w, dw_w, 5e-4)
+    close(d_b, db_w, 5e-4)
+    close(dgamma, dg_w, 5e-4)
+    close(dbeta, dbe_w, 5e-4)
+
+
+def test_softmax_xent_and_top1():
+    b, k = 300, 10
+    logits = rnd(b, k, scale=3.0)
+    labels = torch.randint(0, k, (b,), device=DEV, dtype=torch.int32)
+    lr = logits.clone().requires_grad_(True)
+    want = ref.softmax_xent_mean(lr, labels)
+    (dwant,) = torch.autograd.grad(want, lr)
+    loss = torch.zeros(1, device=DEV)
+    dl = torch.empty_like(logits)
+    correct = torch.zeros(1, device=DEV, dtype=torch.int32)
+    nv.softmax_xent(logits, labels, loss, dl, correct)
+    close(loss, want.reshape(1))
+    close(dl, dwant)
+    hits = ref.top1_hits(logits, labels)
+    assert int(correct.item()) == hits
+    c2 = torch.zeros(1, device=DEV, dtype=torch.int32)
+    nv.top1_count(logits, labels, c2)
+    assert int(c2.item()) == hits
+
+
+@pytest.mark.parametrize("n", [1024, 1663370, 269722 + 3])
+def test_fused_adam_and_momentum(n):
+    p, g = rnd(n), rnd(n, seed=2)
+    m, v = rnd(n, scale=0.1, seed=3), rnd(n, scale=0.1, seed=4).abs()
+    lr_t = ref.adam_lr_t(1e-3, 7)
+    hyper = torch.tensor([lr_t, 0.9, 0.999, 1e-8, 0.125, 0.9, 2e-4, 0.0], device=DEV)
+    pr, mr, vr = p.clone(), m.clone(), v.clone()
+    ref.adam_update(pr, g * 0.125, mr, vr, lr_t)
+    nv.fused_adam(p, g, m, v, hyper)
+    close(p, pr, 1e-5)
+    close(m, mr, 1e-5)
+    close(v, vr, 1e-5)
+    p2, m2 = rnd(n, seed=5), rnd(n, scale=0.1, seed=6)
+    pr2, mr2 = p2.clone(), m2.clone()
+    ref.momentum_update(pr2, g * 0.125, mr2, lr_t, 0.9, 2e-4)
+    nv.fused_momentum_sgd(p2, g, m2, hyper)
+    close(p2, pr2, 1e-5)
+    close(m2, mr2, 1e-5)
+
+
+def test_flat_ops_and_elementwise():
+    n = 100003
+    x = rnd(n)
+    want = x * 0.25
+    close(nv.flat_scale(x.clone(), 0.25), want)
+    sd = torch.tensor([0.25], device=DEV)
+    close(nv.flat_scale(x.clone(), scale_dev=sd), want)
+    y = rnd(n, seed=8)
+    close(nv.flat_axpy(y.clone(), x, -0.5), y - 0.5 * x)
+    a, b = rnd(n, seed=9), rnd(n, seed=10)
+    close(nv.add_relu_fwd(a, b, True), torch.relu(a) + b)
+    close(nv.add_relu_fwd(a, b, False), torch.relu(a + b))
+    d = rnd(n, seed=12)
+    da, db = nv.add_relu_bwd(d, a, b, True)
+    close(da, d * (a > 0))
+    close(db, d)
+    da, db = nv.add_relu_bwd(d, a, b, False)
+    close(da, d * ((a + b) > 0))
+    assert abs(nv.zero_fraction(torch.relu(a)) - float((torch.relu(a) == 0).float().mean())) < 1e-6
+
+
+def test_maxpool_same():
+    for shape in [(3, 28, 28, 32), (3, 14, 14, 64), (2, 7, 7, 8)]:
+        x = rnd(*shape)
+        xr = x.clone().requires_grad_(True)
+        want = ref.max_pool_2x2_same(xr)
+        y, arg = nv.maxpool2x2_fwd(x)
+        close(y, want)
+        dy = rnd(*want.shape, seed=41)
+        (dx_want,) = torch.autograd.grad(want, xr, dy)
+        close(nv.maxpool2x2_bwd(dy, arg, y, tuple(x.shape)), dx_want)
+
+
+def test_dropout_statistics_and_replay():
+    n = 1 << 20
+    x = torch.ones(n, device=DEV)
+    y = nv.dropout(x, 0.5, 66478, 0)
+    keep = float((y != 0).float().mean())
+    assert abs(keep - 0.5) < 5e-3
+    assert torch.all((y == 0) | (y == 2.0))
+    # same (seed, offset) regenerates the same mask (backward pass), another offset does not
+    assert torch.equal(y, nv.dropout(x, 0.5, 66478, 0))
+    assert not torch.equal(y, nv.dropout(x, 0.5, 66478, n // 4))
+
+
+@pytest.mark.parametrize("shape", [(256, 3136, 512), (100, 512, 10), (37, 70, 129)])
+def test_gemm_variants(shape):
+    m, k, n = shape
+    a, b = rnd(m, k), rnd(k, n, seed=3)
+    bias = rnd(n, seed=4)
+    close(nv.gemm(a, b), a @ b)
+    close(nv.gemm(a, b, bias=bias, relu=True), torch.relu(a @ b + bias))
+    close(nv.gemm(a.t().contiguous(), b, trans_a=True), a @ b)
+    close(nv.gemm(a, b.t().contiguous(), trans_b=True), a @ b)
+    out = torch.zeros(n, device=DEV)
+    nv.col_sum(b, out)
+    close(out, b.sum(0))
+
+
+def test_crop_whiten():
+    src = rnd(10, 36, 36, 3, scale=40.0) + 100
+    idx = torch.tensor([3, 1, 7, 7], device=DEV, dtype=torch.int32)
+    offs = torch.tensor([[0, 0], [4, 2], [1, 3], [2, 2]], device=DEV, dtype=torch.int32)
+    got = nv.crop_whiten(src, idx, offs, (32, 32))
+    crops = torch.stack([src[int(i), int(o[0]):int(o[0]) + 32, int(o[1]):int(o[1]) + 32] for i, o in zip(idx, offs)])
+    close(got, ref.per_image_whiten(crops), 1e-3)
+
+
+def test_program_record_run_and_graph_replay():
+    n = 4096
+    x = torch.ones(n, device=DEV)
+    prog = nv.hip().Program()
+    prog.begin_record()
+    nv.flat_scale(x, 2.0)
+    prog.mark_segment()
+    nv.flat_scale(x, 3.0)
+    prog.end_record()
+    assert prog.num_records == 2 and prog.num_segments == 2
+    torch.cuda.synchronize()
+    assert float(x[0]) == 1.0  # recording does not launch
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        prog.run(s.cuda_stream)
+        s.synchronize()
+        assert float(x[5]) == 6.0
+        prog.run(s.cuda_stream, 1)
+        s.synchronize()
+        assert float(x[5]) == 18.0
+        prog.instantiate(s.cuda_stream)
+        prog.replay(s.cuda_stream)
+        prog.replay(s.cuda_stream)
+        s.synchronize()
+    assert float(x[n - 1]) == 18.0 * 36.0
