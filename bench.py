@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of synchronous data-parallel ResNet CIFAR-10 training.
+
+  python bench.py --gpus N --steps K --warmup W [--model resnet20] [--batch 256]
+
+N > 1 is launched by torchrun (one rank per GPU over RCCL); RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* come from the environment. Every rank trains the same pre-activation ResNet-(6n+2) on
+synthetic CIFAR-shaped data with random-init weights: full forward, backward, gradient
+all-reduce (bucketed, overlapped with backward) and the fused Adam update, all inside the timed
+region, in fp32 (the reference's dtype) on the exact-fp32 matrix cores. Scaling is weak: the
+per-GPU batch is fixed. Rank 0 prints one JSON line.
+
+Reference workload: DistributedResNet/src/distributed_train.py (sync-replica Adam training of
+the CIFAR ResNet, batch 256 per worker in DistributedResNet/tools/tf_ec2.py:88).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+MODELS = {"resnet8": 1, "resnet20": 3, "resnet32": 5, "resnet56": 9, "resnet110": 18}
+
+
+def cpu_floor(model: str):
+    try:
+        with open(os.path.join(ROOT, "bench", "cpu_floor.json")) as f:
+            d = json.load(f)
+        if d.get("model") == model:
+            return float(d["images_per_sec"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--model", default="resnet20", choices=sorted(MODELS))
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--optimizer", default="adam", choices=["adam", "momentum"])
+    ap.add_argument("--buckets", type=int, default=3, help="gradient buckets overlapped with backward (N>1)")
+    ap.add_argument("--no-graph", action="store_true", help="issue kernels one by one instead of hipGraph replay")
+    ap.add_argument("--lr", type=float, default=1e-3)
+    args = ap.parse_args()
+
+    from distributed_tensorflow_amd.models.resnet_hip import ResNetHipStep
+    from distributed_tensorflow_amd.ops import reference as ref
+    from distributed_tensorflow_amd.parallel.comm import Communicator
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; for the CPU floor run bench/cpu_reference.py")
+    comm = Communicator.from_env()
+    world = comm.world
+    if world != args.gpus and comm.is_chief:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    n = MODELS[args.model]
+    torch.manual_seed(1234 + comm.rank)
+
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        step = ResNetHipStep(n, args.batch, optimizer=args.optimizer, num_buckets=args.buckets if world > 1 else 1)
+        # identical initial parameters on every replica
+        comm.broadcast(step.arena.params, 0)
+        images = torch.randn(args.batch, 32, 32, 3, device=comm.device)
+        labels = torch.randint(0, 10, (args.batch,), device=comm.device)
+        step.load_batch(images, labels)
+        graph = not args.no_graph
+        if graph:
+            step.instantiate(per_segment=world > 1)
+        nseg = step.num_segments
+        ranges = step.bucket_ranges
+        grads = step.arena.grads
+        t_global = 0
+
+        def one_step() -> None:
+            nonlocal t_global
+            t_global += 1
+            step.set_hyper(lr_t=ref.adam_lr_t(args.lr, t_global) if args.optimizer == "adam" else args.lr,
+                           grad_scale=1.0 / world, momentum=0.9, weight_decay=2e-4)
+            if world == 1:
+                step.run(-1, graph)
+                return
+            for i in range(nseg - 1):
+                step.run(i, graph)
+                lo, hi = ranges[i]
+                comm.all_reduce_async(grads[lo:hi])
+            comm.wait_all()
+            step.run(nseg - 1, graph)
+
+        for _ in range(args.warmup):
+            one_step()
+        stream.synchronize()
+        comm.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        stream.synchronize()
+        torch.cuda.synchronize()
+        comm.barrier()
+        dt = time.perf_counter() - t0
+        loss = step.loss_value()
+
+    t = torch.tensor([dt], device=comm.device, dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if comm.is_chief:
+        ms = dt / args.steps * 1e3
+        value = args.batch * world * args.steps / dt
+        floor = cpu_floor(args.model)
+        print(json.dumps({
+            "metric": "images/sec (node) ResNet CIFAR-10 sync-SGD",
+            "value": round(value, 1),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": round(value / floor, 2) if floor else None,
+            "dtype": "fp32",
+            "data": "synthetic CIFAR-10-shaped images, random-init weights",
+            "config": {
+                "model": args.model, "global_batch": args.batch * world, "per_gpu_batch": args.batch,
+                "seq_len": None, "image": "32x32x3", "optimizer": args.optimizer,
+                "parallelism": f"dp{world}", "hip_graph": graph, "grad_buckets": len(ranges),
+                "kernels_per_step": step.kernel_count, "final_loss": round(loss, 4),
+                "baseline": "CPU reference floor (bench/cpu_floor.json); the reference publishes no numbers",
+            },
+        }))
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()

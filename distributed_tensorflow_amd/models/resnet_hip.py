@@ -1,0 +1,318 @@
+"""Fused MI355X training/eval step of the CIFAR ResNet, recorded as a step program.
+
+The whole step is a flat list of ~(6n+1)*4 kernel launches over pre-allocated buffers:
+
+  forward   one implicit-GEMM conv kernel per layer; the producer's BatchNorm+ReLU is applied
+            while the input tile is staged into LDS, the residual add (identity / option-A /
+            BN+ReLU'd stem) and the NEXT BatchNorm's batch statistics are fused into the
+            epilogue. No normalised activation is ever written to HBM.
+  head      BN+ReLU+global-average-pool+FC+softmax-cross-entropy in one kernel.
+  backward  per conv: filter gradient (input re-activated on the fly), data gradient whose
+            epilogue applies the ReLU mask and accumulates BatchNorm-backward's two reductions,
+            then one elementwise kernel that finishes BatchNorm-backward and adds the shortcut
+            gradient.
+  update    one fused Adam (or momentum-SGD + weight decay) launch over the flat arena.
+
+The program is recorded once (no launches), then replayed either from C++ or as a hipGraph.
+Segment marks split the backward pass at stage boundaries so the gradient buckets of the
+already finished layers can be all-reduced while the rest of backward still runs.
+
+Reference behaviour reproduced: DistributedResNet/src/resnet.py (model),
+DistributedResNet/src/distributed_train.py:119-129,237,256 (loss, Adam, gradients).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ..ops import native as nv
+from ..ops.reference import BN_EPSILON, same_pad
+from ..runtime.arena import ParamArena
+from .resnet import NUM_CLASSES, resnet_blocks, resnet_param_specs
+
+PACK_DTYPE = np.dtype(
+    [("w_off", "<i8"), ("out_off", "<i8"), ("ks", "<i4"), ("Cin", "<i4"), ("Cout", "<i4"), ("flip", "<i4"),
+     ("n_floats", "<i4"), ("first_block", "<i4")]
+)
+
+
+@dataclass
+class _Bn:
+    fwd: nv.BnState        # statistics of the BN input tensor
+    gsums: torch.Tensor    # float64 [2C] backward reductions
+    gamma_name: str
+    beta_name: str
+
+
+class ResNetHipStep:
+    """Owns the buffers and the recorded program of one replica's training step."""
+
+    def __init__(self, n: int, batch: int, arena: Optional[ParamArena] = None, *, optimizer: str = "adam",
+                 num_buckets: int = 1, num_classes: int = NUM_CLASSES, training: bool = True,
+                 device: str | torch.device = "cuda"):
+        nv.require()
+        if optimizer not in ("adam", "momentum"):
+            raise ValueError("optimizer must be 'adam' or 'momentum'")
+        self.n, self.batch, self.num_classes = n, batch, num_classes
+        self.device = torch.device(device)
+        self.training = training
+        self.optimizer = optimizer
+        if arena is None:
+            slots = ("m", "v") if optimizer == "adam" else ("m",)
+            arena = ParamArena(resnet_param_specs(n, num_classes), self.device, slots if training else ())
+            arena.initialize()
+        self.arena = arena
+        self.blocks = resnet_blocks(n)
+        dev, B = self.device, batch
+        f32 = dict(device=dev, dtype=torch.float32)
+
+        # ---- I/O and scalars
+        self.images = torch.zeros((B, 32, 32, 3), **f32)
+        self.labels = torch.zeros(B, device=dev, dtype=torch.int32)
+        self.scalars = torch.zeros(4, **f32)                  # [0] = loss
+        self.loss = self.scalars[0:1]
+        self.correct = torch.zeros(4, device=dev, dtype=torch.int32)[0:1]
+        self.hyper = torch.zeros(nv.HYPER_SLOTS, **f32)
+        self.hyper_host = torch.zeros(nv.HYPER_SLOTS, dtype=torch.float32).pin_memory()
+        self.feat = torch.empty((B, 64), **f32)
+        self.logits = torch.empty((B, num_classes), **f32)
+        self.dlogits = torch.empty((B, num_classes), **f32)
+
+        # ---- activations kept for backward: raw conv outputs / block sums only
+        self.c0 = torch.empty((B, 32, 32, 16), **f32)
+        self.c1: List[torch.Tensor] = []
+        self.y: List[torch.Tensor] = []
+        for blk in self.blocks:
+            hw = blk.conv2.in_hw
+            self.c1.append(torch.empty((B, hw, hw, blk.conv1.cout), **f32))
+            self.y.append(torch.empty((B, hw, hw, blk.conv2.cout), **f32))
+
+        # ---- BatchNorm statistics arena (fp64), zeroed once per step
+        bn_channels = [16] + [c for blk in self.blocks for c in (([] if blk.first_block else [blk.conv1.cin]) + [blk.conv2.cin])] + [64]
+        self.stats = torch.zeros(sum(4 * c for c in bn_channels), device=dev, dtype=torch.float64)
+        self._stat_off = 0
+        a = arena
+        self.bn0 = self._make_bn(16, B * 32 * 32, "conv0/gamma", "conv0/beta")
+        self.bn1: List[Optional[_Bn]] = []
+        self.bn2: List[_Bn] = []
+        for blk in self.blocks:
+            if blk.first_block:
+                self.bn1.append(None)
+            else:
+                hw = blk.conv1.in_hw
+                self.bn1.append(self._make_bn(blk.conv1.cin, B * hw * hw, blk.conv1.bn_gamma, blk.conv1.bn_beta))
+            hw = blk.conv2.in_hw
+            self.bn2.append(self._make_bn(blk.conv2.cin, B * hw * hw, blk.conv2.bn_gamma, blk.conv2.bn_beta))
+        self.bnf = self._make_bn(64, B * 8 * 8, "fc/gamma", "fc/beta")
+
+        # ---- packed filters (forward order, and flipped/transposed for the data gradient)
+        entries = []
+        off = 0
+        self._pk_fwd: Dict[str, Tuple[int, int]] = {}
+        self._pk_bwd: Dict[str, Tuple[int, int]] = {}
+        convs = [("conv0/conv", 3, 16)] + [(c.weight, c.cin, c.cout) for blk in self.blocks for c in (blk.conv1, blk.conv2)]
+        for name, cin, cout in convs:
+            nfl = nv.packed_floats(3, cin, cout, False)
+            self._pk_fwd[name] = (off, nfl)
+            entries.append((a.offsets[name], off, 3, cin, cout, 0, nfl))
+            off += nfl
+            if training and name != "conv0/conv":
+                nfl = nv.packed_floats(3, cin, cout, True)
+                self._pk_bwd[name] = (off, nfl)
+                entries.append((a.offsets[name], off, 3, cin, cout, 1, nfl))
+                off += nfl
+        self.packed = torch.empty(off, **f32)
+        table = np.zeros(len(entries), dtype=PACK_DTYPE)
+        blk0 = 0
+        for i, (w_off, out_off, ks, cin, cout, flip, nfl) in enumerate(entries):
+            table[i] = (w_off, out_off, ks, cin, cout, flip, nfl, blk0)
+            blk0 += (nfl + 255) // 256
+        assert PACK_DTYPE.itemsize == nv.hip().PACK_ENTRY_BYTES
+        self._pack_blocks = blk0
+        self._pack_table = torch.from_numpy(table.view(np.uint8).copy()).to(dev)
+        self._pack_n = len(entries)
+
+        # ---- backward scratch: three rotating gradient buffers of the largest activation
+        if training:
+            big = B * 32 * 32 * 16
+            self._gbuf = [torch.empty(big, **f32) for _ in range(3)]
+
+        self.bucket_ranges: List[Tuple[int, int]] = []
+        self.program = nv.hip().Program()
+        self._record(num_buckets)
+        self._graph_ready = False
+        self.set_hyper(lr_t=0.0)
+
+    # ------------------------------------------------------------------------------------------
+    def _make_bn(self, c: int, count: int, gamma: str, beta: str) -> _Bn:
+        o = self._stat_off
+        self._stat_off += 4 * c
+        st = nv.BnState(self.stats[o:o + 2 * c], self.arena.param(gamma), self.arena.param(beta), count, BN_EPSILON)
+        return _Bn(st, self.stats[o + 2 * c:o + 4 * c], gamma, beta)
+
+    def _wpk(self, name: str, bwd: bool = False) -> torch.Tensor:
+        off, n = (self._pk_bwd if bwd else self._pk_fwd)[name]
+        return self.packed[off:off + n]
+
+    def _view(self, buf: torch.Tensor, shape) -> torch.Tensor:
+        n = 1
+        for s in shape:
+            n *= s
+        return buf[:n].view(shape)
+
+    # ------------------------------------------------------------------------------------------
+    def _record_forward(self) -> None:
+        a = self.arena
+        nv.hip().pack_multi(a.params.data_ptr(), self.packed.data_ptr(), self._pack_table.data_ptr(), self._pack_n,
+                            self._pack_blocks, nv.stream())
+        nv.conv_fprop(self.images, self._wpk("conv0/conv"), ks=3, cout=16, out=self.c0, out_sums=self.bn0.fwd.sums)
+        x, x_bn = self.c0, self.bn0
+        for k, blk in enumerate(self.blocks):
+            bn1 = self.bn0 if blk.first_block else self.bn1[k]
+            bn2 = self.bn2[k]
+            nxt = self.bn1[k + 1] if k + 1 < len(self.blocks) else self.bnf
+            nv.conv_fprop(x, self._wpk(blk.conv1.weight), ks=3, cout=blk.conv1.cout, stride=blk.conv1.stride,
+                          in_bn=bn1.fwd, out=self.c1[k], out_sums=bn2.fwd.sums)
+            if blk.first_block:
+                res = dict(res_mode=nv.RES_BNRELU, res=x, res_bn=self.bn0.fwd)
+            elif blk.increase_dim:
+                res = dict(res_mode=nv.RES_SHORTCUT_A, res=x)
+            else:
+                res = dict(res_mode=nv.RES_IDENT, res=x)
+            nv.conv_fprop(self.c1[k], self._wpk(blk.conv2.weight), ks=3, cout=blk.conv2.cout, in_bn=bn2.fwd,
+                          out=self.y[k], out_sums=nxt.fwd.sums, **res)
+            x = self.y[k]
+        nv.head_fwd(x, self.bnf.fwd, a.param("fc/fc_weights"), a.param("fc/fc_bias"), self.labels, self.feat,
+                    self.logits, self.dlogits, self.loss, self.correct)
+
+    def _record_backward(self, num_buckets: int) -> None:
+        a = self.arena
+        blocks = self.blocks
+        # bucket split points (float offsets into the flat arena), by parameter volume
+        marks: Dict[int, int] = {}
+        if num_buckets > 1:
+            total = a.total
+            targets = [total * i // num_buckets for i in range(1, num_buckets)]
+            for tgt in targets:
+                # the block whose first parameter offset is closest to the target from above
+                best = None
+                for k, blk in enumerate(blocks):
+                    first = blk.conv1.bn_beta or blk.conv1.weight
+                    o = a.offsets[first]
+                    if o >= tgt and (best is None or o < best[1]):
+                        best = (k, o)
+                if best is not None and best[0] > 0:
+                    marks[best[0]] = best[1]
+        hi = a.total
+
+        dY, G, G2 = self._gbuf
+        x_last = self.y[-1]
+        g = self._view(G, x_last.shape)
+        nv.head_bwd(x_last, self.bnf.fwd, a.param("fc/fc_weights"), self.feat, self.dlogits, g, self.bnf.gsums,
+                    a.grad("fc/fc_weights"), a.grad("fc/fc_bias"))
+        dy = nv.bn_bwd_apply(g, x_last, self.bnf.fwd, self.bnf.gsums, dgamma=a.grad("fc/gamma"), dbeta=a.grad("fc/beta"),
+                             out=self._view(dY, x_last.shape))
+        bufs = [dY, G, G2]  # bufs[0] always holds the current block-output gradient
+        for k in range(len(blocks) - 1, -1, -1):
+            blk = blocks[k]
+            x_in = self.c0 if k == 0 else self.y[k - 1]
+            bn1 = self.bn0 if blk.first_block else self.bn1[k]
+            bn2 = self.bn2[k]
+            c1 = self.c1[k]
+            dy = self._view(bufs[0], self.y[k].shape)
+            # conv2: filter gradient, masked data gradient, BN backward
+            nv.conv_wgrad(c1, dy, a.grad(blk.conv2.weight), stride=1, in_bn=bn2.fwd)
+            g2 = nv.conv_fprop(dy, self._wpk(blk.conv2.weight, True), ks=3, cout=blk.conv2.cin, pad=1,
+                               out_hw=(c1.shape[1], c1.shape[2]), epi_mode=nv.EPI_MASK, mask_src=c1, mask_bn=bn2.fwd,
+                               out_sums=bn2.gsums, out=self._view(bufs[1], c1.shape))
+            dc1 = nv.bn_bwd_apply(g2, c1, bn2.fwd, bn2.gsums, dgamma=a.grad(bn2.gamma_name), dbeta=a.grad(bn2.beta_name), out=g2)
+            # conv1
+            s = blk.conv1.stride
+            nv.conv_wgrad(x_in, dc1, a.grad(blk.conv1.weight), stride=s, in_bn=bn1.fwd)
+            _, pb, _ = same_pad(x_in.shape[1], 3, s)
+            g1 = nv.conv_fprop(dc1, self._wpk(blk.conv1.weight, True), ks=3, cout=blk.conv1.cin, stride=1,
+                               upsample=(s == 2), pad=2 - pb, out_hw=(x_in.shape[1], x_in.shape[2]),
+                               epi_mode=nv.EPI_MASK, mask_src=x_in, mask_bn=bn1.fwd,
+                               extra=dy if blk.first_block else None,
+                               out_sums=bn1.gsums, out=self._view(bufs[2], x_in.shape))
+            if blk.first_block:
+                res = dict(res_mode=nv.BWD_RES_NONE)
+            elif blk.increase_dim:
+                res = dict(res_mode=nv.BWD_RES_SHORTCUT_A, res=dy)
+            else:
+                res = dict(res_mode=nv.BWD_RES_IDENT, res=dy)
+            nv.bn_bwd_apply(g1, x_in, bn1.fwd, bn1.gsums, dgamma=a.grad(bn1.gamma_name), dbeta=a.grad(bn1.beta_name),
+                            out=g1, **res)
+            bufs = [bufs[2], bufs[1], bufs[0]]
+            if k in marks:
+                self.bucket_ranges.append((marks[k], hi))
+                hi = marks[k]
+                self.program.mark_segment()
+        # stem: filter gradient of conv0 from the raw images
+        dc0 = self._view(bufs[0], self.c0.shape)
+        nv.conv_wgrad(self.images, dc0, a.grad("conv0/conv"), stride=1)
+        self.bucket_ranges.append((0, hi))
+        self.program.mark_segment()
+
+    def _record(self, num_buckets: int) -> None:
+        a = self.arena
+        p = self.program
+        p.begin_record()
+        try:
+            nv.memset_zero(self.stats)
+            nv.memset_zero(self.scalars)
+            nv.hip().memset(self.correct.data_ptr(), 0, 16, nv.stream())
+            if self.training:
+                nv.memset_zero(a.grads)
+            self._record_forward()
+            if self.training:
+                self._record_backward(num_buckets)
+                if self.optimizer == "adam":
+                    nv.fused_adam(a.params, a.grads, a.slots["m"], a.slots["v"], self.hyper)
+                else:
+                    nv.fused_momentum_sgd(a.params, a.grads, a.slots["m"], self.hyper)
+        finally:
+            p.end_record()
+        self.num_segments = p.num_segments
+
+    # ------------------------------------------------------------------------------------------
+    def set_hyper(self, lr_t: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                  grad_scale: float = 1.0, momentum: float = 0.9, weight_decay: float = 0.0) -> None:
+        """Stages the step-dependent scalars; ordered on the current stream before the next replay."""
+        h = self.hyper_host
+        h[0], h[1], h[2], h[3], h[4], h[5], h[6] = lr_t, beta1, beta2, eps, grad_scale, momentum, weight_decay
+        self.hyper.copy_(h, non_blocking=True)
+
+    def load_batch(self, images: torch.Tensor, labels: torch.Tensor) -> None:
+        self.images.copy_(images, non_blocking=True)
+        self.labels.copy_(labels.to(torch.int32), non_blocking=True)
+
+    def instantiate(self, per_segment: bool = False) -> None:
+        s = torch.cuda.current_stream().cuda_stream
+        if per_segment:
+            for i in range(self.num_segments):
+                self.program.instantiate(s, i)
+        else:
+            self.program.instantiate(s, -1)
+        self._graph_ready = True
+
+    def run(self, seg: int = -1, graph: bool = True) -> None:
+        """Enqueues the whole step (seg < 0) or one segment on the current stream."""
+        s = torch.cuda.current_stream().cuda_stream
+        if graph and self.program.instantiated(seg):
+            self.program.replay(s, seg)
+        else:
+            self.program.run(s, seg)
+
+    def loss_value(self) -> float:
+        return float(self.loss.item())
+
+    def correct_count(self) -> int:
+        return int(self.correct.item())
+
+    @property
+    def kernel_count(self) -> int:
+        return self.program.num_records
