@@ -129,21 +129,28 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(ConvFpropArgs a) {
   }
   __syncthreads();
 
-  // ---- per-lane epilogue coefficients -------------------------------------------------
-  float e_scale[NT], e_shift[NT], e_mean[NT], e_rstd[NT], e_bias[NT];
+  // ---- per-lane epilogue coefficients: the MFMA operands are swapped (filter as A, pixels as
+  // B), so a lane's four accumulator registers are output channels 4q..4q+3 of ONE pixel (l15):
+  // the epilogue moves 16 contiguous bytes per lane and 16 consecutive pixels per instruction.
+  float e_scale[NT][4], e_shift[NT][4], e_mean[NT][4], e_rstd[NT][4], e_bias[NT][4];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int co = (z * NT + j) * 16 + l15;
-    e_scale[j] = 1.f; e_shift[j] = 0.f; e_mean[j] = 0.f; e_rstd[j] = 1.f; e_bias[j] = 0.f;
-    if (co < a.Cout) {
-      if (a.res_mode == RES_BNRELU) bn_coeffs(a.res_bn, co, a.Cout, e_scale[j], e_shift[j], e_mean[j], e_rstd[j]);
-      if (a.epi_mode == EPI_MASK) bn_coeffs(a.mask_bn, co, a.Cout, e_scale[j], e_shift[j], e_mean[j], e_rstd[j]);
-      if (a.epi_mode == EPI_BIAS_RELU || a.epi_mode == EPI_BIAS) e_bias[j] = a.bias[co];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = (z * NT + j) * 16 + 4 * q + r;
+      e_scale[j][r] = 1.f; e_shift[j][r] = 0.f; e_mean[j][r] = 0.f; e_rstd[j][r] = 1.f; e_bias[j][r] = 0.f;
+      if (co < a.Cout) {
+        if (a.res_mode == RES_BNRELU)
+          bn_coeffs(a.res_bn, co, a.Cout, e_scale[j][r], e_shift[j][r], e_mean[j][r], e_rstd[j][r]);
+        if (a.epi_mode == EPI_MASK)
+          bn_coeffs(a.mask_bn, co, a.Cout, e_scale[j][r], e_shift[j][r], e_mean[j][r], e_rstd[j][r]);
+        if (a.epi_mode == EPI_BIAS_RELU || a.epi_mode == EPI_BIAS) e_bias[j][r] = a.bias[co];
+      }
     }
   }
-  float st1[NT], st2[NT];
+  floatx4 st1[NT], st2[NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) { st1[j] = 0.f; st2[j] = 0.f; }
+  for (int j = 0; j < NT; ++j) { st1[j] = floatx4{0.f, 0.f, 0.f, 0.f}; st2[j] = floatx4{0.f, 0.f, 0.f, 0.f}; }
 
   // ---- main loop over this wave's M-tiles ------------------------------------------
   const int tile_px = a.TH * a.TW;
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(ConvFpropArgs a) {
 #pragma unroll
             for (int i = 0; i < MTW; ++i)
 #pragma unroll
-              for (int j = 0; j < NT; ++j) acc[i][j] = DTF_MFMA16(av[i][s], bv[j][s], acc[i][j]);
+              for (int j = 0; j < NT; ++j) acc[i][j] = DTF_MFMA16(bv[j][s], av[i][s], acc[i][j]);
         }
       }
     } else {
@@ -204,71 +211,84 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(ConvFpropArgs a) {
 #pragma unroll
           for (int i = 0; i < MTW; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = DTF_MFMA16(av[i][s], bv[j][s], acc[i][j]);
+            for (int j = 0; j < NT; ++j) acc[i][j] = DTF_MFMA16(bv[j][s], av[i][s], acc[i][j]);
       }
     }
 
-    // ---- epilogue: lane holds pixels 4q..4q+3 of each M-tile, channel l15 of each N-tile
+    // ---- epilogue: lane holds channels 4q..4q+3 (per N-tile) of pixel l15 of each M-tile
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
+      const int p = (mb + i) * 16 + l15;
+      const int ty = p / a.TW;
+      const int tx = p - ty * a.TW;
+      const int oy = oy0 + ty, ox = ox0 + tx;
+      const bool pok = (p < tile_px) && (oy < a.Ho) && (ox < a.Wo);
+      const size_t pbase = ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int p = (mb + i) * 16 + 4 * q + r;
-        const int ty = p / a.TW;
-        const int tx = p - ty * a.TW;
-        const int oy = oy0 + ty, ox = ox0 + tx;
-        const bool pok = (p < tile_px) && (oy < a.Ho) && (ox < a.Wo);
-        const size_t pbase = ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout;
+      for (int j = 0; j < NT; ++j) {
+        const int co = (z * NT + j) * 16 + 4 * q;
+        if (!pok || co >= a.Cout) continue;
+        floatx4 v = acc[i][j];
+        const size_t idx = pbase + co;
+        if (a.res_mode == RES_IDENT) {
+          v += *reinterpret_cast<const floatx4*>(a.res + idx);
+        } else if (a.res_mode == RES_BNRELU) {
+          const floatx4 rv = *reinterpret_cast<const floatx4*>(a.res + idx);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int co = (z * NT + j) * 16 + l15;
-          if (!pok || co >= a.Cout) continue;
-          float v = acc[i][j][r];
-          const size_t idx = pbase + co;
-          if (a.res_mode == RES_IDENT) {
-            v += a.res[idx];
-          } else if (a.res_mode == RES_BNRELU) {
-            v += fmaxf(a.res[idx] * e_scale[j] + e_shift[j], 0.f);
-          } else if (a.res_mode == RES_SHORTCUT_A) {
-            const int cres = a.Cout >> 1, cq = a.Cout >> 2;
-            if (co >= cq && co < cq + cres) {
-              const int rc = co - cq;
-              const int RW = a.Wo * 2;
-              const float* rp = a.res + ((size_t)(n * a.Ho * 2 + oy * 2) * RW + ox * 2) * cres + rc;
-              v += 0.25f * (rp[0] + rp[cres] + rp[(size_t)RW * cres] + rp[(size_t)RW * cres + cres]);
-            }
+          for (int r = 0; r < 4; ++r) v[r] += fmaxf(rv[r] * e_scale[j][r] + e_shift[j][r], 0.f);
+        } else if (a.res_mode == RES_SHORTCUT_A) {
+          const int cres = a.Cout >> 1, cq = a.Cout >> 2;
+          if (co >= cq && co < cq + cres) {
+            const int RW = a.Wo * 2;
+            const float* rp = a.res + ((size_t)(n * a.Ho * 2 + oy * 2) * RW + ox * 2) * cres + (co - cq);
+            const floatx4 r0 = *reinterpret_cast<const floatx4*>(rp);
+            const floatx4 r1 = *reinterpret_cast<const floatx4*>(rp + cres);
+            const floatx4 r2 = *reinterpret_cast<const floatx4*>(rp + (size_t)RW * cres);
+            const floatx4 r3 = *reinterpret_cast<const floatx4*>(rp + (size_t)RW * cres + cres);
+            v += (r0 + r1 + r2 + r3) * 0.25f;
           }
-          if (a.epi_mode == EPI_BIAS_RELU) {
-            v = fmaxf(v + e_bias[j], 0.f);
-          } else if (a.epi_mode == EPI_BIAS) {
-            v += e_bias[j];
-          } else if (a.epi_mode == EPI_MASK) {
-            const float x = a.mask_src[idx];
-            if (a.extra) v += a.extra[idx];
-            v = (x * e_scale[j] + e_shift[j] > 0.f) ? v : 0.f;
-            st1[j] += v;
-            st2[j] += v * ((x - e_mean[j]) * e_rstd[j]);
-          }
-          if (a.epi_mode != EPI_MASK) {
-            st1[j] += v;
-            st2[j] += v * v;
-          }
-          a.out[idx] = v;
         }
+        if (a.epi_mode == EPI_BIAS_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r] + e_bias[j][r], 0.f);
+        } else if (a.epi_mode == EPI_BIAS) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += e_bias[j][r];
+        } else if (a.epi_mode == EPI_MASK) {
+          const floatx4 x = *reinterpret_cast<const floatx4*>(a.mask_src + idx);
+          if (a.extra) v += *reinterpret_cast<const floatx4*>(a.extra + idx);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = (x[r] * e_scale[j][r] + e_shift[j][r] > 0.f) ? v[r] : 0.f;
+            st1[j][r] += v[r];
+            st2[j][r] += v[r] * ((x[r] - e_mean[j][r]) * e_rstd[j][r]);
+          }
+        }
+        if (a.epi_mode != EPI_MASK) {
+          st1[j] += v;
+          st2[j] += v * v;
+        }
+        *reinterpret_cast<floatx4*>(a.out + idx) = v;
       }
     }
   }
 
-  // ---- statistics: reduce over the four lane quarters, then waves, then blocks ---------
+  // ---- statistics: reduce over the 16 pixel lanes, then waves (LDS), then blocks (fp64 atomics)
   if (a.out_sums) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      float v1 = st1[j], v2 = st2[j];
-      v1 += __shfl_xor(v1, 16); v1 += __shfl_xor(v1, 32);
-      v2 += __shfl_xor(v2, 16); v2 += __shfl_xor(v2, 32);
-      if (q == 0) {
-        atomicAdd(&s_stat[j * 16 + l15], v1);
-        atomicAdd(&s_stat[NT * 16 + j * 16 + l15], v2);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v1 = st1[j][r], v2 = st2[j][r];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+          v1 += __shfl_xor(v1, off);
+          v2 += __shfl_xor(v2, off);
+        }
+        if (l15 == 0) {
+          atomicAdd(&s_stat[j * 16 + 4 * q + r], v1);
+          atomicAdd(&s_stat[NT * 16 + j * 16 + 4 * q + r], v2);
+        }
       }
     }
     __syncthreads();
@@ -361,6 +381,7 @@ size_t conv_fprop(const ConvFpropArgs& a_in, int ks, hipStream_t stream) {
   const int s = a.upsample ? 1 : a.stride;
   if (a.nt_total <= 0) a.nt_total = ceil_div(a.Cout, 16);
   if ((a.Cin & 3) != 0 && a.Cin > 4) throw std::runtime_error("conv_fprop: Cin must be <=4 or a multiple of 4");
+  if (a.Cout & 3) throw std::runtime_error("conv_fprop: Cout must be a multiple of 4");
   // Shrink the tile until the smallest configuration fits.
   while (lds_bytes(ks, s, cp, 1, a.TH, a.TW) > 160 * 1024 && a.TH > 1) {
     a.TH = (a.TH + 1) / 2;

@@ -99,14 +99,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
   const float inv_hw = 1.f / (float)a.HW;
   for (int c = tid; c < C; c += 256) {
     float d = 0.f;
-    const float f = a.feat[(size_t)n * C + c];
-    for (int k = 0; k < K; ++k) {
-      d += s_dz[k] * a.fc_w[c * K + k];
-      atomicAdd(&a.d_fc_w[c * K + k], f * s_dz[k]);
-    }
+    for (int k = 0; k < K; ++k) d += s_dz[k] * a.fc_w[c * K + k];
     s_df[c] = d * inv_hw;
   }
-  if (tid < K) atomicAdd(&a.d_fc_b[tid], s_dz[tid]);
   __syncthreads();
   const floatx4* x4 = reinterpret_cast<const floatx4*>(a.x + (size_t)n * a.HW * C);
   floatx4* g4 = reinterpret_cast<floatx4*>(a.g + (size_t)n * a.HW * C);
@@ -131,6 +126,28 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
   }
   __syncthreads();
   for (int cc = tid; cc < 2 * C; cc += 256) atomicAdd(&a.gsums[cc], (double)s_red[cc]);
+}
+
+// FC parameter gradients: one thread per (c, k) element walks the batch; dW[c][k] = sum_n
+// feat[n][c] * dz[n][k], db[k] = sum_n dz[n][k]. The batch is split over gridDim.y blocks that
+// combine with one atomic per element.
+__global__ __launch_bounds__(256) void head_param_grad_kernel(HeadBwdArgs a) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int C = a.C, K = a.K;
+  const int per = (a.B + gridDim.y - 1) / gridDim.y;
+  const int n0 = blockIdx.y * per;
+  const int n1 = (n0 + per < a.B) ? n0 + per : a.B;
+  if (e < C * K) {
+    const int c = e / K, k = e - c * K;
+    float s = 0.f;
+    for (int n = n0; n < n1; ++n) s += a.feat[(size_t)n * C + c] * a.dlogits[(size_t)n * K + k];
+    atomicAdd(&a.d_fc_w[e], s);
+  } else if (e < C * K + K) {
+    const int k = e - C * K;
+    float s = 0.f;
+    for (int n = n0; n < n1; ++n) s += a.dlogits[(size_t)n * K + k];
+    atomicAdd(&a.d_fc_b[k], s);
+  }
 }
 
 __global__ __launch_bounds__(256) void softmax_xent_kernel(SoftmaxXentArgs a) {
@@ -180,6 +197,8 @@ void head_bwd(const HeadBwdArgs& a, hipStream_t stream) {
   if (a.K > kMaxK || a.C > kMaxC || (a.C & 3) || (256 % (a.C / 4)) != 0)
     throw std::runtime_error("head_bwd: unsupported C/K");
   launch("head_bwd", head_bwd_kernel, dim3(a.B), dim3(256), 0, stream, a);
+  const int splits = a.B >= 64 ? 8 : 1;
+  launch("head_param_grad", head_param_grad_kernel, dim3(ceil_div(a.C * a.K + a.K, 256), splits), dim3(256), 0, stream, a);
 }
 
 void softmax_xent(const SoftmaxXentArgs& a, hipStream_t stream) {
