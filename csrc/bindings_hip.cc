@@ -212,7 +212,7 @@ PYBIND11_MODULE(_hip, m) {
   });
   m.def("dropout", [](const py::dict& d, uint64_t stream) {
     DropoutArgs a{};
-    P(x, const float); P(y, float); V(n); V(keep_prob); V(seed); V(offset);
+    P(x, const float); P(y, float); V(n); V(keep_prob); V(seed); V(offset); P(offset_dev, const unsigned long long);
     dropout_apply(a, as_stream(stream));
   });
   m.def("gemm_f32", [](const py::dict& d, uint64_t stream) {

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(DropoutArgs a) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   const float inv_keep = 1.f / a.keep_prob;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const unsigned long long cidx = a.offset + (unsigned long long)i;
+    const unsigned long long cidx = a.offset + (a.offset_dev ? *a.offset_dev : 0ull) + (unsigned long long)i;
     uint32_t ctr[4] = {(uint32_t)cidx, (uint32_t)(cidx >> 32), 0u, 0u};
     uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
 #pragma unroll

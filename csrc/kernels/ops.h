@@ -143,7 +143,8 @@ void maxpool2x2_bwd(const MaxPoolBwdArgs& a, hipStream_t stream);
 
 // dropout with a counter-based Philox-4x32-10 stream: mask regenerated from (seed, offset)
 // in backward (reference: DistributedLeNet/src/mnist.py:139-140, keep_prob 0.5, seed 66478)
-struct DropoutArgs { const float* x; float* y; long long n; float keep_prob; unsigned long long seed; unsigned long long offset; };
+struct DropoutArgs { const float* x; float* y; long long n; float keep_prob; unsigned long long seed; unsigned long long offset;
+                     const unsigned long long* offset_dev; };   // offset_dev (nullable): added to offset, read at run time so a replayed program draws a new mask per step
 void dropout_apply(const DropoutArgs& a, hipStream_t stream);   // same kernel for fwd (x) and bwd (dy)
 
 // fp32 GEMM on MFMA: C[M,N] = op(A) * op(B) (+bias[N]) (relu) ; row-major storage

@@ -1,0 +1,115 @@
+"""MI355X training/eval step of the MNIST LeNet, recorded as a step program.
+
+forward   conv1/conv2 = implicit-GEMM MFMA kernels with fused bias + ReLU, 2x2 SAME max pools that
+          keep a 2-bit argmax, FC1 = split-K MFMA GEMM with bias + ReLU, Philox dropout whose mask
+          is regenerated (not stored) in backward, FC2 GEMM with bias, fused softmax
+          cross-entropy that also emits d(loss)/d(logits).
+backward  explicit chain of GEMM (NT / TN forms), dropout replay, ReLU masks (the pooled maximum
+          doubles as the ReLU mask of its winner), max-pool scatter, conv data/filter gradients,
+          column sums for the biases; gradients land in the flat arena, one fused Adam launch.
+
+Reference behaviour reproduced: DistributedLeNet/src/mnist.py:76-164 (model, loss, top-1 count)
+and DistributedLeNet/src/distributed_train.py:164 (Adam).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ..ops import native as nv
+from ..runtime.arena import ParamArena
+from ..runtime.step_program import StepProgramBase
+from .lenet import DROPOUT_KEEP, NUM_LABELS, SEED, lenet_param_specs
+
+
+class LeNetHipStep(StepProgramBase):
+    def __init__(self, batch: int, arena: Optional[ParamArena] = None, *, optimizer: str = "adam", num_buckets: int = 1,
+                 training: bool = True, device: str | torch.device = "cuda", dropout: bool = True):
+        nv.require()
+        self.batch, self.training, self.optimizer = batch, training, optimizer
+        self.device = torch.device(device)
+        self.dropout = dropout and training
+        if arena is None:
+            slots = ("m", "v") if optimizer == "adam" else ("m",)
+            arena = ParamArena(lenet_param_specs(), self.device, slots if training else ())
+            arena.initialize()
+        self.arena = arena
+        B, dev = batch, self.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        self._init_common((28, 28, 1))
+        a = arena
+        self.wpk1 = torch.empty(nv.packed_floats(5, 1, 32, False), **f32)
+        self.wpk2 = torch.empty(nv.packed_floats(5, 32, 64, False), **f32)
+        self.wpk2_t = torch.empty(nv.packed_floats(5, 32, 64, True), **f32)
+        self.a1 = torch.empty((B, 28, 28, 32), **f32)
+        self.a2 = torch.empty((B, 14, 14, 64), **f32)
+        self.h = torch.empty((B, 512), **f32)
+        self.hd = torch.empty((B, 512), **f32)
+        self.logits = torch.empty((B, NUM_LABELS), **f32)
+        self.dlogits = torch.empty((B, NUM_LABELS), **f32)
+        if training:
+            self.dh = torch.empty((B, 512), **f32)
+            self.dp2 = torch.empty((B, 7 * 7 * 64), **f32)
+            self.dp1 = torch.empty((B, 14, 14, 32), **f32)
+        self._record(num_buckets)
+        self.set_hyper(lr_t=0.0)
+        self.set_step_counter(0)
+
+    def _record(self, num_buckets: int) -> None:
+        a = self.arena
+        p = self.program
+        B = self.batch
+        p.begin_record()
+        try:
+            self._record_prologue()
+            nv.pack_weights(a.param("conv1_weights"), False, self.wpk1)
+            nv.pack_weights(a.param("conv2_weights"), False, self.wpk2)
+            # ---------------- forward
+            nv.conv_fprop(self.images, self.wpk1, ks=5, cout=32, epi_mode=nv.EPI_BIAS_RELU, bias=a.param("conv1_biases"), out=self.a1)
+            self.p1, self.arg1 = nv.maxpool2x2_fwd(self.a1)
+            nv.conv_fprop(self.p1, self.wpk2, ks=5, cout=64, epi_mode=nv.EPI_BIAS_RELU, bias=a.param("conv2_biases"), out=self.a2)
+            self.p2, self.arg2 = nv.maxpool2x2_fwd(self.a2)
+            flat = self.p2.view(B, -1)
+            nv.gemm(flat, a.param("fc1_weights"), bias=a.param("fc1_biases"), relu=True, out=self.h)
+            if self.dropout:
+                nv.dropout(self.h, DROPOUT_KEEP, SEED, 0, out=self.hd, offset_dev=self.step_counter[0:1])
+                hd = self.hd
+            else:
+                hd = self.h
+            nv.gemm(hd, a.param("fc2_weights"), bias=a.param("fc2_biases"), out=self.logits)
+            nv.softmax_xent(self.logits, self.labels, self.loss, self.dlogits if self.training else None, self.correct)
+            if self.training:
+                # ---------------- backward
+                nv.pack_weights(a.param("conv2_weights"), True, self.wpk2_t)
+                nv.gemm(hd, self.dlogits, trans_a=True, out=a.grad("fc2_weights"))
+                nv.col_sum(self.dlogits, a.grad("fc2_biases"))
+                nv.gemm(self.dlogits, a.param("fc2_weights"), trans_b=True, out=self.dh)
+                if self.dropout:
+                    nv.dropout(self.dh, DROPOUT_KEEP, SEED, 0, out=self.dh, offset_dev=self.step_counter[0:1])
+                nv.relu_bwd(self.dh, self.h, out=self.dh)
+                nv.gemm(flat, self.dh, trans_a=True, out=a.grad("fc1_weights"))
+                nv.col_sum(self.dh, a.grad("fc1_biases"))
+                # the FC block holds 97 % of the parameters: its bucket is final here
+                if num_buckets > 1:
+                    lo = a.offsets["fc1_weights"]
+                    self.bucket_ranges.append((lo, a.total))
+                    p.mark_segment()
+                else:
+                    lo = a.total
+                nv.gemm(self.dh, a.param("fc1_weights"), trans_b=True, out=self.dp2)
+                da2 = nv.maxpool2x2_bwd(self.dp2.view(B, 7, 7, 64), self.arg2, self.p2, (B, 14, 14, 64), relu_mask=True)
+                self.da2 = da2
+                nv.conv_wgrad(self.p1, da2, a.grad("conv2_weights"), stride=1)
+                nv.col_sum(da2.view(-1, 64), a.grad("conv2_biases"))
+                nv.conv_fprop(da2, self.wpk2_t, ks=5, cout=32, pad=2, out_hw=(14, 14), out=self.dp1)
+                da1 = nv.maxpool2x2_bwd(self.dp1, self.arg1, self.p1, (B, 28, 28, 32), relu_mask=True)
+                self.da1 = da1
+                nv.conv_wgrad(self.images, da1, a.grad("conv1_weights"), stride=1)
+                nv.col_sum(da1.view(-1, 32), a.grad("conv1_biases"))
+                self.bucket_ranges.append((0, lo))
+                p.mark_segment()
+                self._record_optimizer()
+        finally:
+            p.end_record()
+        self.num_segments = p.num_segments

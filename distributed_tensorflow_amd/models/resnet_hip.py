@@ -31,6 +31,7 @@ import torch
 from ..ops import native as nv
 from ..ops.reference import BN_EPSILON, same_pad
 from ..runtime.arena import ParamArena
+from ..runtime.step_program import StepProgramBase
 from .resnet import NUM_CLASSES, resnet_blocks, resnet_param_specs
 
 PACK_DTYPE = np.dtype(
@@ -47,7 +48,7 @@ class _Bn:
     beta_name: str
 
 
-class ResNetHipStep:
+class ResNetHipStep(StepProgramBase):
     """Owns the buffers and the recorded program of one replica's training step."""
 
     def __init__(self, n: int, batch: int, arena: Optional[ParamArena] = None, *, optimizer: str = "adam",
@@ -69,14 +70,7 @@ class ResNetHipStep:
         dev, B = self.device, batch
         f32 = dict(device=dev, dtype=torch.float32)
 
-        # ---- I/O and scalars
-        self.images = torch.zeros((B, 32, 32, 3), **f32)
-        self.labels = torch.zeros(B, device=dev, dtype=torch.int32)
-        self.scalars = torch.zeros(4, **f32)                  # [0] = loss
-        self.loss = self.scalars[0:1]
-        self.correct = torch.zeros(4, device=dev, dtype=torch.int32)[0:1]
-        self.hyper = torch.zeros(nv.HYPER_SLOTS, **f32)
-        self.hyper_host = torch.zeros(nv.HYPER_SLOTS, dtype=torch.float32).pin_memory()
+        self._init_common((32, 32, 3))
         self.feat = torch.empty((B, 64), **f32)
         self.logits = torch.empty((B, num_classes), **f32)
         self.dlogits = torch.empty((B, num_classes), **f32)
@@ -140,10 +134,7 @@ class ResNetHipStep:
             big = B * 32 * 32 * 16
             self._gbuf = [torch.empty(big, **f32) for _ in range(3)]
 
-        self.bucket_ranges: List[Tuple[int, int]] = []
-        self.program = nv.hip().Program()
         self._record(num_buckets)
-        self._graph_ready = False
         self.set_hyper(lr_t=0.0)
 
     # ------------------------------------------------------------------------------------------
@@ -258,61 +249,15 @@ class ResNetHipStep:
         self.program.mark_segment()
 
     def _record(self, num_buckets: int) -> None:
-        a = self.arena
         p = self.program
         p.begin_record()
         try:
             nv.memset_zero(self.stats)
-            nv.memset_zero(self.scalars)
-            nv.hip().memset(self.correct.data_ptr(), 0, 16, nv.stream())
-            if self.training:
-                nv.memset_zero(a.grads)
+            self._record_prologue()
             self._record_forward()
             if self.training:
                 self._record_backward(num_buckets)
-                if self.optimizer == "adam":
-                    nv.fused_adam(a.params, a.grads, a.slots["m"], a.slots["v"], self.hyper)
-                else:
-                    nv.fused_momentum_sgd(a.params, a.grads, a.slots["m"], self.hyper)
+                self._record_optimizer()
         finally:
             p.end_record()
         self.num_segments = p.num_segments
-
-    # ------------------------------------------------------------------------------------------
-    def set_hyper(self, lr_t: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
-                  grad_scale: float = 1.0, momentum: float = 0.9, weight_decay: float = 0.0) -> None:
-        """Stages the step-dependent scalars; ordered on the current stream before the next replay."""
-        h = self.hyper_host
-        h[0], h[1], h[2], h[3], h[4], h[5], h[6] = lr_t, beta1, beta2, eps, grad_scale, momentum, weight_decay
-        self.hyper.copy_(h, non_blocking=True)
-
-    def load_batch(self, images: torch.Tensor, labels: torch.Tensor) -> None:
-        self.images.copy_(images, non_blocking=True)
-        self.labels.copy_(labels.to(torch.int32), non_blocking=True)
-
-    def instantiate(self, per_segment: bool = False) -> None:
-        s = torch.cuda.current_stream().cuda_stream
-        if per_segment:
-            for i in range(self.num_segments):
-                self.program.instantiate(s, i)
-        else:
-            self.program.instantiate(s, -1)
-        self._graph_ready = True
-
-    def run(self, seg: int = -1, graph: bool = True) -> None:
-        """Enqueues the whole step (seg < 0) or one segment on the current stream."""
-        s = torch.cuda.current_stream().cuda_stream
-        if graph and self.program.instantiated(seg):
-            self.program.replay(s, seg)
-        else:
-            self.program.run(s, seg)
-
-    def loss_value(self) -> float:
-        return float(self.loss.item())
-
-    def correct_count(self) -> int:
-        return int(self.correct.item())
-
-    @property
-    def kernel_count(self) -> int:
-        return self.program.num_records

@@ -472,11 +472,16 @@ def maxpool2x2_bwd(dy, arg, y, x_shape, relu_mask: bool = False):
     return dx
 
 
-def dropout(x, keep_prob: float, seed: int, offset: int, out=None):
+def dropout(x, keep_prob: float, seed: int, offset: int, out=None, offset_dev=None):
+    """Philox dropout; the same (seed, offset[, *offset_dev]) regenerates the same mask, which is
+    how the backward pass applies it to the gradient without storing it."""
     require()
     if out is None:
         out = torch.empty_like(x)
-    hip().dropout(dict(x=_chk(x, "x"), y=_chk(out, "y"), n=x.numel(), keep_prob=float(keep_prob), seed=int(seed), offset=int(offset)), stream())
+    d = dict(x=_chk(x, "x"), y=_chk(out, "y"), n=x.numel(), keep_prob=float(keep_prob), seed=int(seed), offset=int(offset))
+    if offset_dev is not None:
+        d["offset_dev"] = _chk(offset_dev, "offset_dev", torch.int64)
+    hip().dropout(d, stream())
     return out
 
 

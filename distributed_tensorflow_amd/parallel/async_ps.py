@@ -1,0 +1,230 @@
+"""Asynchronous SGD over one-sided, staleness-bounded parameter shards.
+
+The reference only sketches asynchronous training (reference: backup_worker_optimizer.py:44-51
+docstring; `num_replicas_to_aggregate=1` in cfg/50_workers/50_workers_1_aggregate_sync:10) on top
+of TensorFlow's ConditionalAccumulator, whose rule is: a gradient tagged with a local step older
+than the accumulator's global step is dropped. Here that rule becomes a first-class mode without a
+parameter-server process:
+
+  * the flat parameter arena is cut into `world` contiguous shards; replica r OWNS shard r: the
+    authoritative parameters and the Adam slots of that range live in r's memory (HBM on a GPU);
+  * every replica maps every owner's shard and a per-sender gradient inbox (CUDA IPC over xGMI
+    between GPUs of one node, a shared file mapping between CPU processes);
+  * pull = one-sided read of all shards; push = one-sided write of each gradient slice into the
+    owner's inbox followed by a doorbell (local step of the pull) on the shared-memory board;
+  * the owner applies a pushed gradient immediately iff `shard_version - pushed_step <= tau`
+    (staleness bound; tau = 0 is the accumulator's "drop anything stale" rule) and bumps the shard
+    version; otherwise the gradient is dropped. No replica ever waits for another replica's
+    compute: waiting only happens when an inbox slot is still unread, bounded by a timeout.
+"""
+from __future__ import annotations
+
+import os
+import time
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from ..ops import reference as ref
+from .comm import Communicator
+
+
+def _shm_tensor(name: str, numel: int, create: bool) -> torch.Tensor:
+    path = os.path.join("/dev/shm", name)
+    if create:
+        with open(path, "wb") as f:
+            f.truncate(max(4, numel * 4))
+    else:
+        deadline = time.time() + 60
+        while not os.path.exists(path) or os.path.getsize(path) < numel * 4:
+            if time.time() > deadline:
+                raise RuntimeError(f"shared region {path} never appeared")
+            time.sleep(0.005)
+    return torch.from_file(path, shared=True, size=max(1, numel), dtype=torch.float32)
+
+
+@dataclass
+class AsyncStats:
+    pushed: int = 0
+    applied: int = 0
+    dropped_stale: int = 0
+    push_waits: int = 0
+
+
+class AsyncParameterShards:
+    """Shard ownership, peer mappings and the push / pull / apply protocol."""
+
+    def __init__(self, replica, comm: Communicator, board, staleness_bound: int, name: str, lr_fn,
+                 push_timeout_s: float = 30.0):
+        if board is None:
+            raise ValueError("asynchronous shards need the shared-memory control board")
+        self.replica, self.comm, self.board = replica, comm, board
+        self.tau = max(0, int(staleness_bound))
+        self.rank, self.world = comm.rank, comm.world
+        self.arena = replica.arena
+        self.bounds = self.arena.shard_bounds(self.world)
+        self.lr_fn = lr_fn
+        self.push_timeout_s = push_timeout_s
+        self.stats = AsyncStats()
+        self.on_gpu = self.arena.params.is_cuda
+        self._name = name.strip("/").replace("/", "_")
+        self._pulled_version: List[int] = [0] * self.world
+        self._files: List[str] = []
+        self._map_regions()
+
+    # ------------------------------------------------------------------------------------------
+    def _map_regions(self) -> None:
+        lo, hi = self.bounds[self.rank]
+        n_own = hi - lo
+        if self.on_gpu:
+            self._map_cuda_ipc(n_own)
+        else:
+            # owner creates its regions, everybody maps all of them
+            for s in range(self.world):
+                self._files.append(f"{self._name}_inbox_{self.rank}_{s}")
+                _shm_tensor(self._files[-1], n_own, True)
+            self._files.append(f"{self._name}_shard_{self.rank}")
+            own = _shm_tensor(self._files[-1], n_own, True)
+            own.copy_(self.arena.params[lo:hi])
+            self.comm.barrier()
+            self.shards = []
+            self.inboxes: List[List[torch.Tensor]] = []
+            for o in range(self.world):
+                n_o = self.bounds[o][1] - self.bounds[o][0]
+                self.shards.append(_shm_tensor(f"{self._name}_shard_{o}", n_o, False))
+                self.inboxes.append([_shm_tensor(f"{self._name}_inbox_{o}_{s}", n_o, False) for s in range(self.world)])
+            self.comm.barrier()
+
+    def _map_cuda_ipc(self, n_own: int) -> None:
+        from torch.multiprocessing.reductions import reduce_tensor
+
+        dev = self.arena.params.device
+        own_shard = torch.empty(max(1, n_own), device=dev, dtype=torch.float32)
+        lo, hi = self.bounds[self.rank]
+        own_shard[:n_own].copy_(self.arena.params[lo:hi])
+        own_inbox = [torch.zeros(max(1, n_own), device=dev, dtype=torch.float32) for _ in range(self.world)]
+        torch.cuda.synchronize()
+        self._own_keepalive = (own_shard, own_inbox)
+        handles = (reduce_tensor(own_shard), [reduce_tensor(t) for t in own_inbox])
+        all_handles = self.comm.all_gather_object(handles)
+        self.shards, self.inboxes = [], []
+        for o, (h_shard, h_inbox) in enumerate(all_handles):
+            if o == self.rank:
+                self.shards.append(own_shard)
+                self.inboxes.append(own_inbox)
+                continue
+            fn, args = h_shard
+            # rebuild on THIS process's device (peer mapping of the owner's memory)
+            self.shards.append(fn(*args))
+            self.inboxes.append([f(*a) for (f, a) in h_inbox])
+        self.comm.barrier()
+
+    # ------------------------------------------------------------------------------------------
+    def pull(self) -> None:
+        """One-sided read of every shard into the local parameter arena."""
+        p = self.arena.params
+        with self.replica.stream_ctx():
+            for o, (lo, hi) in enumerate(self.bounds):
+                self._pulled_version[o] = self.board.shard_version(o)
+                if hi > lo:
+                    p[lo:hi].copy_(self.shards[o][: hi - lo], non_blocking=True)
+        self.replica.synchronize()
+
+    def push(self) -> None:
+        """One-sided write of each gradient slice into its owner's inbox + doorbell."""
+        g = self.arena.grads
+        for k in range(self.world):
+            o = (self.rank + k) % self.world  # start with the own shard, spread the peers
+            lo, hi = self.bounds[o]
+            deadline = time.time() + self.push_timeout_s
+            while self.board.poll_doorbell(o, self.rank) >= 0:
+                # the owner has not consumed the previous push yet
+                self.stats.push_waits += 1
+                self.service()
+                if time.time() > deadline or self.board.should_stop():
+                    break
+                time.sleep(0.0002)
+            if self.board.poll_doorbell(o, self.rank) >= 0:
+                continue  # still busy: this gradient slice is dropped
+            if hi > lo:
+                with self.replica.stream_ctx():
+                    self.inboxes[o][self.rank][: hi - lo].copy_(g[lo:hi], non_blocking=True)
+                self.replica.synchronize()
+            self.board.ring_doorbell(o, self.rank, self._pulled_version[o])
+            self.stats.pushed += 1
+
+    def service(self) -> int:
+        """Applies (or drops) every gradient waiting in this replica's inbox; returns #applied."""
+        me = self.rank
+        lo, hi = self.bounds[me]
+        n = hi - lo
+        applied = 0
+        for s in range(self.world):
+            pushed_step = self.board.poll_doorbell(me, s)
+            if pushed_step < 0:
+                continue
+            version = self.board.shard_version(me)
+            if version - pushed_step <= self.tau:
+                if n > 0:
+                    self._apply(self.inboxes[me][s][:n], version)
+                self.board.bump_shard_version(me)
+                applied += 1
+                self.stats.applied += 1
+                if me == 0:
+                    self.board.set_global_step(self.board.shard_version(0))
+            else:
+                self.stats.dropped_stale += 1
+            self.board.clear_doorbell(me, s)
+        return applied
+
+    def _apply(self, grad: torch.Tensor, version: int) -> None:
+        a = self.arena
+        lo, hi = self.bounds[self.rank]
+        lr = self.lr_fn(version)
+        shard = self.shards[self.rank][: hi - lo]
+        opt = self.replica.optimizer
+        if self.on_gpu:
+            from ..ops import native as nv
+
+            with self.replica.stream_ctx():
+                hyper = torch.tensor(
+                    [ref.adam_lr_t(lr, version + 1) if opt == "adam" else lr, 0.9, 0.999, 1e-8, 1.0,
+                     self.replica.momentum, self.replica.weight_decay, 0.0], dtype=torch.float32).to(grad.device)
+                if opt == "adam":
+                    nv.fused_adam(shard, grad, a.slots["m"][lo:hi], a.slots["v"][lo:hi], hyper)
+                else:
+                    nv.fused_momentum_sgd(shard, grad, a.slots["m"][lo:hi], hyper)
+            self.replica.synchronize()
+        else:
+            if opt == "adam":
+                ref.adam_update(shard, grad, a.slots["m"][lo:hi], a.slots["v"][lo:hi], ref.adam_lr_t(lr, version + 1))
+            else:
+                ref.momentum_update(shard, grad, a.slots["m"][lo:hi], lr, self.replica.momentum, self.replica.weight_decay)
+
+    # ------------------------------------------------------------------------------------------
+    def step(self) -> Tuple[float, int]:
+        """One asynchronous worker iteration; returns (loss, global_step)."""
+        self.service()
+        self.pull()
+        self.replica.forward_backward()
+        self.replica.synchronize()
+        self.push()
+        self.service()
+        return self.replica.loss_value(), self.board.global_step()
+
+    def drain(self, timeout_s: float = 30.0) -> None:
+        """End of training: keep servicing until every replica has stopped pushing."""
+        self.board.barrier(timeout_s)
+        self.service()
+        self.board.barrier(timeout_s)
+        self.pull()
+
+    def close(self) -> None:
+        for f in self._files:
+            try:
+                os.unlink(os.path.join("/dev/shm", f))
+            except OSError:
+                pass
+        self._files = []

@@ -49,7 +49,12 @@ class ParamArena:
             off += (s.numel + ALIGN_FLOATS - 1) // ALIGN_FLOATS * ALIGN_FLOATS
         self.total = off
         self.params = torch.zeros(self.total, dtype=torch.float32, device=self.device)
-        self.grads = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        # The gradient buffer carries a small tail that the optimizer never touches: strategies
+        # put per-step scalars there (e.g. "my gradient is part of this update") so they travel
+        # in the same collective as the gradients.
+        self.grads_full = torch.zeros(self.total + ALIGN_FLOATS, dtype=torch.float32, device=self.device)
+        self.grads = self.grads_full[: self.total]
+        self.aux = self.grads_full[self.total:]
         self.slots: Dict[str, torch.Tensor] = {k: torch.zeros_like(self.params) for k in slots}
         self._by_name = {s.name: s for s in self.specs}
 

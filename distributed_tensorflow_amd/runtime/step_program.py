@@ -1,0 +1,95 @@
+"""Common machinery of recorded GPU training steps (shared by the ResNet and LeNet programs).
+
+A step program owns: the flat parameter arena, static input buffers (the batch is copied in,
+the program always reads the same addresses so it can be replayed as a hipGraph), a small device
+buffer of step-dependent scalars, the scalar outputs (loss, top-1 count), and the recorded
+`_hip.Program`. Segments of the program end where a gradient bucket becomes final.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+
+from ..ops import native as nv
+
+
+class StepProgramBase:
+    # set by subclasses before _init_common(): self.arena, self.device, self.batch, self.training, self.optimizer
+    def _init_common(self, image_shape: Tuple[int, ...]) -> None:
+        dev, B = self.device, self.batch
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.images = torch.zeros((B,) + tuple(image_shape), **f32)
+        self.labels = torch.zeros(B, device=dev, dtype=torch.int32)
+        self.scalars = torch.zeros(4, **f32)                  # [0] = loss
+        self.loss = self.scalars[0:1]
+        self._correct_buf = torch.zeros(4, device=dev, dtype=torch.int32)
+        self.correct = self._correct_buf[0:1]
+        self.hyper = torch.zeros(nv.HYPER_SLOTS, **f32)
+        self.hyper_host = torch.zeros(nv.HYPER_SLOTS, dtype=torch.float32).pin_memory()
+        self.step_counter = torch.zeros(2, device=dev, dtype=torch.int64)
+        self.step_counter_host = torch.zeros(2, dtype=torch.int64).pin_memory()
+        self.bucket_ranges: List[Tuple[int, int]] = []
+        self.program = nv.hip().Program()
+        self.num_segments = 1
+
+    def _record_prologue(self) -> None:
+        nv.memset_zero(self.scalars)
+        nv.hip().memset(self._correct_buf.data_ptr(), 0, 16, nv.stream())
+        if self.training:
+            nv.memset_zero(self.arena.grads)
+
+    def _record_optimizer(self) -> None:
+        a = self.arena
+        if self.optimizer == "adam":
+            nv.fused_adam(a.params, a.grads, a.slots["m"], a.slots["v"], self.hyper)
+        else:
+            nv.fused_momentum_sgd(a.params, a.grads, a.slots["m"], self.hyper)
+
+    # ------------------------------------------------------------------------------------------
+    def set_hyper(self, lr_t: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                  grad_scale: float = 1.0, momentum: float = 0.9, weight_decay: float = 0.0) -> None:
+        """Stages the step-dependent scalars; ordered on the current stream before the next replay."""
+        h = self.hyper_host
+        h[0], h[1], h[2], h[3], h[4], h[5], h[6] = lr_t, beta1, beta2, eps, grad_scale, momentum, weight_decay
+        self.hyper.copy_(h, non_blocking=True)
+
+    def set_step_counter(self, step: int) -> None:
+        """Device-visible step number (dropout draws a fresh mask per step from it)."""
+        self.step_counter_host[0] = int(step) * (1 << 20)
+        self.step_counter.copy_(self.step_counter_host, non_blocking=True)
+
+    def load_batch(self, images: torch.Tensor, labels: torch.Tensor) -> None:
+        self.images.copy_(images.reshape(self.images.shape), non_blocking=True)
+        self.labels.copy_(labels.to(torch.int32), non_blocking=True)
+
+    def instantiate(self, per_segment: bool = False) -> None:
+        s = torch.cuda.current_stream().cuda_stream
+        if per_segment:
+            for i in range(self.num_segments):
+                self.program.instantiate(s, i)
+        else:
+            self.program.instantiate(s, -1)
+
+    def run(self, seg: int = -1, graph: bool = True) -> None:
+        """Enqueues the whole step (seg < 0) or one segment on the current stream."""
+        s = torch.cuda.current_stream().cuda_stream
+        if graph and self.program.instantiated(seg):
+            self.program.replay(s, seg)
+        else:
+            self.program.run(s, seg)
+
+    def zero_grad_range(self, lo: int, hi: int) -> None:
+        """Zeroes grads[lo:hi] on the current stream (short-circuited backward)."""
+        if hi > lo:
+            nv.memset_zero(self.arena.grads[lo:hi])
+
+    def loss_value(self) -> float:
+        return float(self.loss.item())
+
+    def correct_count(self) -> int:
+        return int(self.correct.item())
+
+    @property
+    def kernel_count(self) -> int:
+        return self.program.num_records

@@ -1,0 +1,289 @@
+"""Training driver: builds the replica, the aggregation policy and the chief services, then runs
+the step loop with the reference's log lines.
+
+Mirrors `train()` of the reference drivers (reference: DistributedLeNet/src/distributed_train.py:105-373,
+DistributedResNet/src/distributed_train.py:182-456, Distributed_test/src/distributed_train.py):
+cluster sanity, chief election (worker 0), staircase learning rate whose decay period is divided
+by the number of aggregated replicas, strategy switch on the method flags, startup barrier,
+optional token wait + timing broadcasts for the worker-time CDF method, NaN guard, per-step
+timeline dumps, the `Worker %d: %s: step %d, loss = %f(%.1f examples/sec; %.3f  sec/batch)` line,
+stop when `step > max_steps`, `Elapsed Time` on the chief and a final checkpoint.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import os
+import random
+import sys
+import time
+from datetime import datetime
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .. import lr as lr_mod
+from ..checkpoint.saver import Saver
+from ..cluster import resolve_task
+from ..data import cifar10 as cifar_data
+from ..data import mnist as mnist_data
+from ..parallel import control_plane
+from ..parallel.comm import Communicator
+from ..parallel.strategies import make_strategy
+from .replica import make_replica
+from .supervisor import Supervisor
+from .timeline import StepTimeline
+
+log = logging.getLogger("dtf")
+
+TRAIN_LINE = "Worker %d: %s: step %d, loss = %f(%.1f examples/sec; %.3f  sec/batch)"
+
+
+def setup_logging(level=logging.INFO) -> None:
+    """tf.logging-like lines on stderr (the launcher redirects them to out_<ROLE_ID>)."""
+    root = logging.getLogger("dtf")
+    if not root.handlers:
+        h = logging.StreamHandler(sys.stderr)
+        h.setFormatter(logging.Formatter("%(levelname)s:dtf:%(message)s"))
+        root.addHandler(h)
+    root.setLevel(level)
+    root.propagate = False
+
+
+class _MnistFeed:
+    def __init__(self, data_dir: str, batch_size: int):
+        self.sets = mnist_data.load_mnist(data_dir)
+        self.batch_size = batch_size
+        self.num_examples = self.sets.train.num_examples
+
+    def next(self):
+        return self.sets.train.next_batch(self.batch_size)
+
+
+class _CifarFeed:
+    def __init__(self, data_dir: str, batch_size: int, padding: int, num_examples: int, seed: Optional[int]):
+        data, labels = cifar_data.prepare_train_data(data_dir, padding)
+        self.batcher = cifar_data.TrainBatcher(data, labels, padding, seed)
+        self.batch_size = batch_size
+        # the LR schedule uses the dataset size flag, not the array length (reference:
+        # DistributedResNet/src/distributed_train.py:213-215)
+        self.num_examples = num_examples if cifar_data.have_files(data_dir) else len(labels)
+
+    def next(self):
+        return self.batcher.next_batch(self.batch_size)
+
+
+def _inject_straggler(flags, rank: int, rng: random.Random) -> None:
+    if flags.inject_straggler_ms <= 0 or not flags.inject_straggler_ranks:
+        return
+    ranks = {int(r) for r in flags.inject_straggler_ranks.split(",") if r.strip()}
+    if rank in ranks and rng.random() < flags.inject_straggler_prob:
+        time.sleep(flags.inject_straggler_ms / 1e3)
+
+
+def ps_main(flags) -> int:
+    """`--job_name=ps`: nothing to host (parameters live in the workers' HBM). Waits for the
+    workers' job to end so reference launch scripts that start a ps process keep working."""
+    log.info("ps task %d: parameters are resident on the worker GPUs; idling until the job ends", flags.task_id)
+    name = flags.board_name
+    if not name:
+        return 0
+    from .. import _host
+
+    try:
+        n_workers = max(1, len([h for h in flags.worker_hosts.split(",") if h.strip()]))
+        board = _host.Board(name, n_workers, False)
+    except RuntimeError:
+        return 0
+    while not board.should_stop():
+        time.sleep(0.2)
+    return 0
+
+
+def train(flags, model: str) -> Dict:
+    """Runs one worker task to completion; returns a summary dict (steps, final loss, ...)."""
+    setup_logging()
+    task = resolve_task(flags.job_name, flags.task_id, flags.ps_hosts, flags.worker_hosts)
+    if task.job_name == "ps":
+        ps_main(flags)
+        return {"role": "ps"}
+    task.export()
+    device = flags.device
+    comm = Communicator.from_env(device="cpu" if device == "cpu" else None)
+    world, rank = comm.world, comm.rank
+    is_chief = rank == 0
+    num_workers = world
+    # Both must be > 0 in a distributed run (reference: distributed_train.py:120-122); the ps
+    # count is only checked for shape since no ps process holds state here.
+    assert num_workers > 0, "num_workers must be > 0"
+    num_replicas_to_aggregate = num_workers if flags.num_replicas_to_aggregate == -1 else flags.num_replicas_to_aggregate
+
+    train_dir = flags.train_dir
+    if is_chief:
+        os.makedirs(train_dir, exist_ok=True)
+
+    # ---- control board (single-node control plane)
+    needs_board = world > 1
+    board = None
+    if needs_board:
+        name = flags.board_name or control_plane.board_name_for(train_dir, task.master_port)
+        board = control_plane.open_board(name, world, rank)
+
+    # ---- data
+    batch_size = flags.batch_size
+    if model == "lenet":
+        feed = _MnistFeed("" if flags.synthetic_data else flags.data_dir, batch_size)
+    else:
+        feed = _CifarFeed("" if flags.synthetic_data else flags.data_dir, batch_size, flags.padding_size,
+                          flags.num_of_instances_cifar10, flags.random_seed + rank)
+    decay_steps = lr_mod.decay_steps(feed.num_examples, batch_size, flags.num_epochs_per_decay, num_replicas_to_aggregate)
+
+    # ---- replica + strategy
+    strategy_needs_segments = flags.interval_method or flags.soft_kill_method or flags.backup_worker_method
+    buckets = max(1, flags.grad_buckets) if (world > 1 or strategy_needs_segments) else 1
+    replica = make_replica(
+        model, batch_size, device, num_residual_blocks=flags.num_residual_blocks, optimizer=flags.optimizer,
+        momentum=flags.momentum, weight_decay=flags.weight_decay if flags.optimizer == "momentum" else 0.0,
+        num_buckets=buckets, use_graph=flags.hip_graph,
+    )
+    saver = Saver(replica.arena, flags.optimizer, flags.checkpoint_names)
+    sv = Supervisor(saver, train_dir, is_chief, flags.save_interval_secs)
+    global_step = 0
+    restored = sv.restore_latest()
+    if restored is not None:
+        global_step = restored
+        replica.updates_applied = restored
+    # non-chief replicas take the chief's state (reference: prepare_or_wait_for_session)
+    with replica.stream_ctx():
+        comm.broadcast(replica.arena.params, 0)
+        for t in replica.arena.slots.values():
+            comm.broadcast(t, 0)
+    replica.synchronize()
+
+    async_mode = flags.async_method
+    if async_mode:
+        from ..parallel.async_ps import AsyncParameterShards
+
+        name = (flags.board_name or control_plane.board_name_for(train_dir, task.master_port)) + "_ps"
+        if board is None:
+            board = control_plane.open_board(name + "_b", world, rank)
+        shards = AsyncParameterShards(
+            replica, comm, board, flags.staleness_bound, name,
+            lambda version: lr_mod.exponential_decay(flags.initial_learning_rate, version, decay_steps, flags.learning_rate_decay_factor),
+        )
+        board.set_global_step(global_step) if is_chief else None
+        strategy = None
+    else:
+        strategy = make_strategy(flags, comm, board, num_replicas_to_aggregate)
+        log.info("Worker %d: aggregation policy %s over %d replicas (aggregate %d)", rank, strategy.name, world, num_replicas_to_aggregate)
+
+    timeout_client, timeout_server = control_plane.launch_manager(board, rank, world, flags.collective_timeout_s)
+    timeline = StepTimeline(rank, enabled=flags.timeline_logging)
+    summary_writer = None
+    if is_chief and flags.should_summarize:
+        from ..utils.summary import FileWriter
+
+        summary_writer = FileWriter(train_dir)
+    next_summary_time = time.time() + flags.save_summaries_secs
+    begin_time = time.time()
+    cur_iteration = -1
+    rng = random.Random(flags.random_seed * 1000 + rank)
+    loss_value = float("nan")
+    cdf = flags.worker_times_cdf_method
+    if cdf and board is not None and is_chief:
+        for r in range(world):
+            board.put_tokens(r, 1, global_step)   # init tokens (reference: get_init_tokens_op)
+    aborted_steps = excluded_steps = 0
+
+    while not sv.should_stop():
+        log.info("A new iteration...")
+        cur_iteration += 1
+        if cdf:
+            if board is not None:
+                tok = board.take_token(rank, flags.collective_timeout_s)   # opt._wait_op
+                if tok is None:
+                    break
+            timeout_client.broadcast_worker_dequeued_token(cur_iteration)
+        start_time = time.time()
+        images, labels = feed.next()
+        replica.load_batch(images, labels)
+        _inject_straggler(flags, rank, rng)
+        timeline.reset()
+        log.info("RUNNING SESSION... %f" % time.time())
+        if async_mode:
+            with timeline.span("async_step"):
+                loss_value, step = shards.step()
+            if board.global_step() > flags.max_steps:
+                board.request_stop()
+        else:
+            lr = lr_mod.exponential_decay(flags.initial_learning_rate, global_step, decay_steps, flags.learning_rate_decay_factor)
+            with timeline.span("train_step", getattr(replica, "stream", None)):
+                res = strategy.step(replica, cur_iteration, lr)
+            if res.applied:
+                global_step += 1
+            aborted_steps += int(res.aborted)
+            excluded_steps += int(not res.included)
+            step = global_step
+            if board is not None and is_chief:
+                board.set_global_step(global_step)
+        log.info("DONE RUNNING SESSION...")
+        if cdf:
+            timeout_client.broadcast_worker_finished_computing_gradients(cur_iteration)
+            if is_chief:
+                deadline = time.time() + 5.0
+                while not timeout_server.collect(cur_iteration) and time.time() < deadline:
+                    time.sleep(0.0005)
+                timeout_server.maybe_report(cur_iteration)
+                if board is not None:
+                    for r in range(world):
+                        board.put_tokens(r, 1, global_step)
+                timeout_client.broadcast_parameters_updated(global_step)
+
+        log_now = flags.log_every <= 1 or cur_iteration % flags.log_every == 0
+        if log_now and not async_mode:
+            loss_value = replica.loss_value()
+        if log_now:
+            assert not math.isnan(loss_value), "Model diverged with loss = NaN"
+        if flags.timeline_logging:
+            timeline.write(train_dir, step)
+        if step > flags.max_steps or (async_mode and board.should_stop()):
+            break
+        duration = time.time() - start_time
+        if log_now:
+            examples_per_sec = batch_size / float(duration)
+            log.info(TRAIN_LINE % (rank, datetime.now(), step, loss_value, examples_per_sec, duration))
+        if is_chief and summary_writer is not None and next_summary_time < time.time():
+            log.info("Running Summary operation on the chief.")
+            scalars = {"loss": loss_value, "learning_rate": lr_mod.exponential_decay(
+                flags.initial_learning_rate, global_step, decay_steps, flags.learning_rate_decay_factor)}
+            summary_writer.add_scalars(scalars, step)
+            log.info("Finished running Summary operation.")
+            next_summary_time += flags.save_summaries_secs
+        sv.maybe_save(step, replica.updates_applied)
+        if board is not None:
+            board.heartbeat(rank)
+
+    if async_mode:
+        shards.drain(flags.collective_timeout_s)
+        global_step = board.global_step()
+        shards.close()
+    replica.synchronize()
+    if is_chief:
+        log.info("Elapsed Time: %f" % (time.time() - begin_time))
+    sv.stop()
+    final = sv.final_save(global_step, replica.updates_applied)
+    if summary_writer is not None:
+        summary_writer.close()
+    comm.barrier()
+    if board is not None and is_chief:
+        board.request_stop()
+    out = {
+        "role": "worker", "rank": rank, "world": world, "global_step": global_step, "iterations": cur_iteration + 1,
+        "loss": loss_value, "checkpoint": final, "aborted_steps": aborted_steps, "excluded_steps": excluded_steps,
+        "strategy": "async" if async_mode else strategy.name,
+    }
+    if async_mode:
+        out["async_stats"] = vars(shards.stats)
+    comm.close()
+    return out
