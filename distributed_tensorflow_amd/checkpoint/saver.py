@@ -38,8 +38,9 @@ _DT_OF = {np.dtype(np.float32): _host.DT_FLOAT, np.dtype(np.float64): _host.DT_D
 def write_bundle(prefix: str, tensors: Dict[str, np.ndarray]) -> None:
     w = _host.BundleWriter(prefix)
     for name, arr in tensors.items():
+        shape = list(np.shape(arr))                 # taken first: ascontiguousarray turns 0-d into 1-d
         arr = np.ascontiguousarray(arr)
-        w.add(name, _DT_OF[arr.dtype], list(arr.shape), arr)
+        w.add(name, _DT_OF[arr.dtype], shape, arr)
     w.finish()
 
 

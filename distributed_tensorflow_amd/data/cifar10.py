@@ -35,7 +35,8 @@ class _RestrictedUnpickler(pickle.Unpickler):
     _ALLOWED = {
         ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
         ("numpy", "ndarray"), ("numpy", "dtype"), ("builtins", "dict"), ("builtins", "list"),
-        ("__builtin__", "dict"), ("__builtin__", "list"), ("copy_reg", "_reconstructor"), ("builtins", "object"),
+        ("__builtin__", "dict"), ("__builtin__", "list"), ("builtins", "object"),
+        ("_codecs", "encode"),   # how Python 3 pickles the byte payload of an array at protocol <= 2
     }
 
     def find_class(self, module, name):

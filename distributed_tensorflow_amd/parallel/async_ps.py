@@ -215,7 +215,16 @@ class AsyncParameterShards:
         return self.replica.loss_value(), self.board.global_step()
 
     def drain(self, timeout_s: float = 30.0) -> None:
-        """End of training: keep servicing until every replica has stopped pushing."""
+        """End of training: keep servicing the own shard until every replica has stopped pushing
+        (a finished owner must not leave the others' last pushes unread)."""
+        done_mark = -7
+        self.board.set_local_step(self.rank, done_mark)
+        deadline = time.time() + timeout_s
+        while time.time() < deadline:
+            self.service()
+            if all(self.board.local_step(r) == done_mark for r in range(self.world)):
+                break
+            time.sleep(0.0005)
         self.board.barrier(timeout_s)
         self.service()
         self.board.barrier(timeout_s)

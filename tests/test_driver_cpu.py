@@ -1,0 +1,207 @@
+"""End-to-end plumbing on CPU: entry scripts, local cluster launcher, evaluator, log contracts,
+checkpoint resume, control board and telemetry."""
+import glob
+import json
+import os
+import re
+import subprocess
+import sys
+import threading
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from distributed_tensorflow_amd import _host  # noqa: E402
+from distributed_tensorflow_amd.cfg import Cfg  # noqa: E402
+from distributed_tensorflow_amd.checkpoint.saver import latest_checkpoint, read_bundle  # noqa: E402
+
+TRAIN_RE = re.compile(r".*Worker (\d+): .*: step (\d+), loss = ([0-9.eE+-]+)\(([0-9.]+) examples/sec; ([0-9.]+)  sec/batch\)")
+
+
+def _run(args, timeout=300, env=None):
+    e = dict(os.environ)
+    e["OMP_NUM_THREADS"] = "2"
+    e.update(env or {})
+    return subprocess.run([sys.executable] + args, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+
+
+def test_board_arrival_order_mask_and_tokens():
+    name = f"dtf_t_board_{os.getpid()}"
+    b = _host.Board(name, 4, True)
+    peers = [_host.Board(name, 4, False) for _ in range(3)]
+    orders = {}
+
+    def arrive(rank, board):
+        orders[rank] = board.arrive(5, rank, 2)
+
+    ts = [threading.Thread(target=arrive, args=(r, ([b] + peers)[r])) for r in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert sorted(orders.values()) == [0, 1, 2, 3]
+    mask = b.freeze_mask(5)
+    assert bin(mask).count("1") == 2 and all(((mask >> r) & 1) == (orders[r] < 2) for r in range(4))
+    assert b.stop_requested(5) and not b.stop_requested(6) and b.arrivals(5) == 4
+    # step slots are recycled by tag
+    assert b.arrivals(5 + _host.BOARD_RING) == 0
+    with pytest.raises(RuntimeError):
+        b.arrivals(5)
+    # tokens: one per worker per update
+    assert peers[0].take_token(1, 0.05) is None
+    b.put_tokens(1, 1, 42)
+    assert peers[0].take_token(1, 1.0) == 42 and peers[0].token_depth(1) == 0
+    # doorbells and telemetry
+    assert b.ring_doorbell(0, 3, 9) and not b.ring_doorbell(0, 3, 10) and peers[1].poll_doorbell(0, 3) == 9
+    b.clear_doorbell(0, 3)
+    assert b.poll_doorbell(0, 3) == -1
+    b.post_times(2, 30, 100, 250)
+    assert peers[2].get_times(2, 30) == (100, 250) and peers[2].get_times(2, 31) is None
+    # startup barrier
+    assert not b.all_ready()
+    for r in range(4):
+        b.mark_ready(r)
+    assert peers[0].wait_all_ready(1.0)
+
+
+def test_single_worker_train_logs_checkpoint_and_resume(tmp_path):
+    d = str(tmp_path / "train")
+    args = ["DistributedLeNet/src/mnist_distributed_train.py", "--synthetic_data", "--device=cpu", "--batch_size=16",
+            "--max_steps=6", f"--train_dir={d}", "--initial_learning_rate=0.001", "--save_interval_secs=1000",
+            "--timeline_logging=true", "--should_summarize=true", "--save_summaries_secs=0"]
+    r = _run(args)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [m for m in (TRAIN_RE.match(l) for l in r.stderr.splitlines()) if m]
+    steps = [int(m.group(2)) for m in lines]
+    assert steps == list(range(1, 7))                      # stop once step > max_steps (one extra step, like the reference)
+    assert "Elapsed Time:" in r.stderr
+    # benchmark.py's regex sees the same step numbers
+    assert [int(m.group(1)) for m in (re.match(".*step ([0-9]*),.*", l) for l in r.stderr.splitlines()) if m] == steps
+    prefix = latest_checkpoint(d)
+    assert prefix.endswith("model.ckpt-7")
+    ck = read_bundle(prefix)
+    assert int(ck["global_step"]) == 7 and "Variable_7/Adam_1" in ck and "beta2_power" in ck
+    # chrome-trace timelines with the reference's file naming
+    tl = sorted(glob.glob(os.path.join(d, "worker=0_timeline_iter=*.json")))
+    assert len(tl) == 7
+    ev = json.load(open(tl[0]))["traceEvents"]
+    assert any(e.get("name") == "train_step" and e.get("ph") == "X" for e in ev)
+    # summaries in TensorBoard's event-file format
+    from distributed_tensorflow_amd.utils.summary import read_events
+
+    events = [e for f in glob.glob(os.path.join(d, "events.out.tfevents.*")) for e in read_events(f)]
+    assert events and "loss" in events[0][1]
+    # relaunching with the same train_dir resumes from the checkpoint
+    r2 = _run([a if not a.startswith("--max_steps") else "--max_steps=9" for a in args])
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert "Restored" in r2.stderr
+    steps2 = [int(m.group(2)) for m in (TRAIN_RE.match(l) for l in r2.stderr.splitlines()) if m]
+    assert steps2 == [8, 9]
+    assert latest_checkpoint(d).endswith("model.ckpt-10")
+
+
+def test_ps_job_is_accepted_and_idles(tmp_path):
+    r = _run(["DistributedLeNet/src/mnist_distributed_train.py", "--job_name=ps", "--task_id=0",
+              "--ps_hosts=127.0.0.1:2222", "--worker_hosts=127.0.0.1:2223", f"--train_dir={tmp_path}"], timeout=60)
+    assert r.returncode == 0 and "parameters are resident" in r.stderr
+
+
+def _local_cfg(name, model, extra_train="", n_workers=1, aggregate=2, max_steps=12):
+    script = "mnist_distributed_train.py" if model == "lenet" else "resnet_distributed_train.py"
+    ev = "mnist_eval.py" if model == "lenet" else "resnet_eval.py"
+    return Cfg({
+        "name": name, "n_masters": 1, "n_workers": n_workers, "n_ps": 1, "n_evaluators": 1,
+        "num_replicas_to_aggregate": str(aggregate), "nfs_mount_point": "/unused", "base_out_dir": "%(nfs_mount_point)s/%(name)s",
+        "batch_size": "16", "initial_learning_rate": ".001", "learning_rate_decay_factor": "0.95", "num_epochs_per_decay": "1.0",
+        "train_commands": [
+            f"sudo python src/{script} --batch_size=%(batch_size)s --initial_learning_rate=%(initial_learning_rate)s "
+            "--learning_rate_decay_factor=%(learning_rate_decay_factor)s --num_epochs_per_decay=%(num_epochs_per_decay)s "
+            f"--train_dir=%(base_out_dir)s/train_dir --worker_hosts='WORKER_HOSTS' --ps_hosts='PS_HOSTS' --task_id=TASK_ID "
+            f"--max_steps={max_steps} --save_interval_secs=1 --num_residual_blocks=1 {extra_train} "
+            "--num_replicas_to_aggregate=%(num_replicas_to_aggregate)s --job_name=JOB_NAME > %(base_out_dir)s/out_ROLE_ID 2>&1 &"
+        ],
+        "evaluate_commands": [
+            "sleep 30",
+            f"python src/{ev} --eval_dir=%(base_out_dir)s/eval_dir --checkpoint_dir=%(base_out_dir)s/train_dir "
+            "--num_residual_blocks=1 > %(base_out_dir)s/out_evaluator 2>&1 &",
+        ],
+    })
+
+
+def test_local_cluster_runs_a_reference_style_cfg_with_evaluator(tmp_path):
+    import benchmark
+    from node_launch import LocalCluster, tf_ec2_run
+
+    cfg = _local_cfg("two_workers_backup", "lenet", "--backup_worker_method=true --worker_times_cdf_method=false", 1, 1, 14)
+    kw = dict(out_root=str(tmp_path), max_workers=2, extra_flags=["--synthetic_data", "--device=cpu"])
+    tf_ec2_run(["node_launch.py", "launch"], cfg, **kw)
+    spec = tf_ec2_run(["node_launch.py", "run_tf"], cfg, **kw)
+    lc = LocalCluster(cfg, **kw)
+    assert set(spec["roles"]) == {"master", "worker0", "evaluator"}
+    assert set(lc.list_running_instances()) <= {"master", "worker0", "evaluator"}
+    assert lc.wait(["master", "worker0"], timeout_s=240)
+    time.sleep(2.5)                                       # evaluator polls once a second
+    assert tf_ec2_run(["node_launch.py", "kill_all_python"], cfg, **kw) >= 0
+    assert lc.list_running_instances() == []
+    base = spec["base_out_dir"]
+    master = open(os.path.join(base, "out_master")).read()
+    worker = open(os.path.join(base, "out_worker0")).read()
+    assert "aggregation policy backup over 2 replicas (aggregate 1)" in master
+    assert benchmark.current_iteration(os.path.join(base, "out_master")) >= 14
+    s0 = [int(m.group(2)) for m in (TRAIN_RE.match(l) for l in master.splitlines()) if m]
+    s1 = [int(m.group(2)) for m in (TRAIN_RE.match(l) for l in worker.splitlines()) if m]
+    assert s0 and s0 == s1                                 # every replica advances on every update
+    ev_out = open(os.path.join(base, "out_evaluator")).read()
+    assert "Succesfully loaded model from" in ev_out and "Precision @ 1:" in ev_out
+    times, losses, precisions, steps = benchmark.extract_times_losses_precision(os.path.join(base, "out_evaluator"))
+    assert len(precisions) >= 1 and len(steps) >= 1 and all(0 <= p <= 1 for p in precisions)
+    got = tf_ec2_run(["node_launch.py", "download_file", spec["cluster_string"], "out_master", str(tmp_path / "dl")], cfg, **kw)
+    assert os.path.exists(got)
+    tf_ec2_run(["node_launch.py", "shutdown"], cfg, **kw)
+
+
+def test_cdf_method_emits_elapsed_and_iteration_times(tmp_path):
+    import benchmark
+    from node_launch import LocalCluster, tf_ec2_run
+
+    cfg = _local_cfg("cdf_run", "lenet", "--worker_times_cdf_method=true", 1, 2, 51)
+    cfg = cfg.with_overrides(n_evaluators=0)
+    kw = dict(out_root=str(tmp_path), max_workers=2, extra_flags=["--synthetic_data", "--device=cpu", "--batch_size=4"])
+    tf_ec2_run(["node_launch.py", "clean_launch_and_run"], cfg, **kw)
+    lc = LocalCluster(cfg, **kw)
+    assert lc.wait(["master", "worker0"], timeout_s=280)
+    out_master = os.path.join(lc.base_out_dir, "out_master")
+    elapsed = benchmark.extract_compute_times(out_master)
+    iters = benchmark.extract_iteration_times(out_master)
+    assert elapsed and all(len(e) == 3 and e[2] > 10 for e in elapsed)
+    assert {e[1] for e in elapsed} == {0, 1}               # both workers reported
+    assert elapsed == sorted(elapsed, key=lambda x: x[0]) and len(iters) >= 30
+    rep = benchmark.print_worker_sorted_times(out_master)
+    assert rep["p99"] >= rep["p50"] > 0
+    lc.shutdown()
+
+
+def test_benchmark_parsers_on_reference_shaped_logs(tmp_path):
+    import benchmark
+
+    m = tmp_path / "out_master"
+    m.write_text(
+        "INFO:dtf:Worker 0: 2026-01-01 00:00:00.1: step 1, loss = 2.302585(512.0 examples/sec; 0.250  sec/batch)\n"
+        "INFO:dtf:Worker 0: 2026-01-01 00:00:00.4: step 2, loss = 2.100000(1024.0 examples/sec; 0.125  sec/batch)\n"
+        "INFO:dtf:ELAPSED TIMES [(0.1, 0, 11), (0.3, 1, 11)]\nINFO:dtf:ITERATION TIMES [0.5, 0.6]\n")
+    e = tmp_path / "out_evaluator"
+    e.write_text("INFO:dtf:Succesfully loaded model from /x/model.ckpt-2 at step=2.\n"
+                 "INFO:dtf:Num examples: 10000  Precision @ 1: 0.912300 Loss: 0.301000 Time: 1.500000\n")
+    assert benchmark.current_iteration(str(m)) == 2
+    assert benchmark.extract_step_times_losses(str(m)) == ([1, 2], [2.302585, 2.1], [0.25, 0.125])
+    assert benchmark.extract_compute_times(str(m)) == [(0.1, 0, 11), (0.3, 1, 11)]
+    assert benchmark.extract_iteration_times(str(m)) == [0.5, 0.6]
+    assert benchmark.extract_times_losses_precision(str(e)) == ([1.5], [0.301], [0.9123], [2])
+    res = benchmark.collect_results({"run": str(tmp_path)})
+    benchmark.plot_time_loss(res, str(tmp_path))
+    benchmark.plot_time_cdfs(res, str(tmp_path))
+    assert os.path.exists(tmp_path / "time_loss.png") and os.path.exists(tmp_path / "step_losses.png") and os.path.exists(tmp_path / "time_cdfs.png")

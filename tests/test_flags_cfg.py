@@ -86,6 +86,7 @@ def test_every_reference_cfg_file_parses_and_expands():
         if "time_cdf" in f:
             assert flags["worker_times_cdf_method"] == "true"
         FLAGS.reset()
+        flags.update(task_id="3", job_name="worker", worker_hosts="a:1,b:2", ps_hosts="c:3")  # launch-time placeholders
         rest = FLAGS.parse([f"--{k}={v}" for k, v in flags.items()])
         assert rest == [], (f, rest)
         ev = cfg_mod.evaluate_flags(c)
