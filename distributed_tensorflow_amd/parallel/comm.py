@@ -93,6 +93,13 @@ class Communicator:
         current stream, so later kernels on the current stream overlap with it."""
         if self.world == 1:
             return
+        if flat.is_cuda and self.info.backend == "gloo":
+            # gloo is the CPU control/test plane: stage device buffers through the host
+            torch.cuda.current_stream().synchronize()
+            host = flat.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+            return
         self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
 
     def wait_all(self) -> None:
@@ -131,7 +138,13 @@ class Communicator:
 
     def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         if self.world > 1:
-            dist.broadcast(t, src=src)
+            if t.is_cuda and self.info.backend == "gloo":
+                torch.cuda.current_stream().synchronize()
+                host = t.detach().cpu()
+                dist.broadcast(host, src=src)
+                t.copy_(host)
+            else:
+                dist.broadcast(t, src=src)
         return t
 
     def barrier(self) -> None:

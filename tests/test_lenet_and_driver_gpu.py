@@ -1,0 +1,150 @@
+"""GPU paths above the kernels: LeNet step program, the replica/strategy stack, the training
+driver, and multi-process modes sharing the one available GPU."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from mp_util import run_workers
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def test_lenet_step_matches_autograd():
+    from distributed_tensorflow_amd.models.lenet import lenet_loss
+    from distributed_tensorflow_amd.models.lenet_hip import LeNetHipStep
+
+    b = 12
+    step = LeNetHipStep(b, dropout=False, num_buckets=2)
+    g = torch.Generator().manual_seed(3)
+    images = torch.rand(b, 28, 28, 1, generator=g) - 0.5
+    labels = torch.randint(0, 10, (b,), generator=g)
+    step.load_batch(images.cuda(), labels.cuda())
+    step.set_hyper(lr_t=0.0)
+    step.run(graph=False)
+    torch.cuda.synchronize()
+    params = {k: v.double().requires_grad_(True) for k, v in step.arena.state_dict().items()}
+    loss = lenet_loss(params, images.double(), labels, train=False)
+    grads = dict(zip(params, torch.autograd.grad(loss, list(params.values()))))
+    assert abs(step.loss_value() - loss.item()) < 1e-4 * max(1, abs(loss.item()))
+    for name, gref in grads.items():
+        assert _rel(step.arena.grad(name), gref) < 2e-3, name
+    assert step.bucket_ranges[0][0] == step.arena.offsets["fc1_weights"] and step.bucket_ranges[-1][0] == 0
+
+
+def test_lenet_dropout_training_reduces_loss_under_graph_replay():
+    from distributed_tensorflow_amd.models.lenet_hip import LeNetHipStep
+    from distributed_tensorflow_amd.ops import reference as ref
+
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        step = LeNetHipStep(64)
+        g = torch.Generator().manual_seed(4)
+        step.load_batch((torch.rand(64, 28, 28, 1, generator=g) - 0.5).cuda(), torch.randint(0, 10, (64,), generator=g).cuda())
+        step.instantiate()
+        losses = []
+        for t in range(1, 31):
+            step.set_hyper(lr_t=ref.adam_lr_t(1e-3, t))
+            step.set_step_counter(t)
+            step.run(graph=True)
+            if t in (1, 30):
+                s.synchronize()
+                losses.append(step.loss_value())
+    assert losses[1] < losses[0]
+
+
+def test_driver_trains_resnet_on_gpu_and_evaluator_scores_it(tmp_path):
+    d = str(tmp_path / "train")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "DistributedResNet/src/resnet_distributed_train.py", "--synthetic_data", "--batch_size=32",
+                        "--num_residual_blocks=1", "--max_steps=12", f"--train_dir={d}", "--initial_learning_rate=0.001",
+                        "--log_every=4"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    steps = [int(m.group(1)) for m in (re.match(r".*step (\d+), loss = ", l) for l in r.stderr.splitlines()) if m]
+    assert steps and steps[-1] >= 9
+    e = subprocess.run([sys.executable, "DistributedResNet/src/resnet_eval.py", "--synthetic_data", "--num_residual_blocks=1",
+                        f"--checkpoint_dir={d}", f"--eval_dir={tmp_path / 'eval'}", "--run_once=true"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert e.returncode == 0, e.stderr[-3000:]
+    assert "Succesfully loaded model from" in e.stderr and "Precision @ 1:" in e.stderr
+
+
+def _gpu_sync_worker(rank, world, board_name, mode):
+    # Several replicas share GPU 0; gloo carries the collectives (RCCL refuses two ranks on one device).
+    import torch
+
+    from distributed_tensorflow_amd.parallel import control_plane
+    from distributed_tensorflow_amd.parallel.comm import Communicator
+    from distributed_tensorflow_amd.parallel.strategies import Backup, FullSync
+    from distributed_tensorflow_amd.train.replica import HipReplica
+
+    os.environ["LOCAL_RANK"] = "0"
+    comm = Communicator.from_env(backend="gloo")
+    board = control_plane.open_board(board_name, world, rank)
+    rep = HipReplica("resnet", 16, num_residual_blocks=1, num_buckets=3)
+    g = torch.Generator().manual_seed(50 + rank)
+    rep.load_batch(torch.randn(16, 32, 32, 3, generator=g), torch.randint(0, 10, (16,), generator=g))
+    control_plane.launch_manager(board, rank, world, 120)
+    strat = FullSync(comm, board) if mode == "sync" else Backup(comm, board, world - 1)
+    losses = []
+    for it in range(6):
+        res = strat.step(rep, it, 1e-3)
+        losses.append(rep.loss_value())
+    rep.synchronize()
+    psum = rep.arena.params.double().sum().item()
+    comm.barrier()
+    comm.close()
+    return dict(losses=losses, psum=psum, updates=rep.updates_applied)
+
+
+@pytest.mark.parametrize("mode", ["sync", "backup"])
+def test_two_gpu_replicas_stay_identical(mode):
+    out = run_workers(_gpu_sync_worker, 2, f"dtf_g_{mode}_{os.getpid()}", mode, timeout=300)
+    assert abs(out[0]["psum"] - out[1]["psum"]) < 1e-6 * max(1.0, abs(out[0]["psum"]))
+    assert all(o["updates"] == 6 for o in out)
+    assert out[0]["losses"][-1] < out[0]["losses"][0]
+
+
+def _gpu_async_worker(rank, world, board_name):
+    import torch
+
+    from distributed_tensorflow_amd.parallel import control_plane
+    from distributed_tensorflow_amd.parallel.async_ps import AsyncParameterShards
+    from distributed_tensorflow_amd.parallel.comm import Communicator
+    from distributed_tensorflow_amd.train.replica import HipReplica
+
+    os.environ["LOCAL_RANK"] = "0"
+    comm = Communicator.from_env(backend="gloo")
+    board = control_plane.open_board(board_name, world, rank)
+    rep = HipReplica("resnet", 16, num_residual_blocks=1)
+    g = torch.Generator().manual_seed(70 + rank)
+    rep.load_batch(torch.randn(16, 32, 32, 3, generator=g), torch.randint(0, 10, (16,), generator=g))
+    control_plane.launch_manager(board, rank, world, 120)
+    shards = AsyncParameterShards(rep, comm, board, 8, board_name + "_ps", lambda v: 1e-3)
+    losses = [shards.step()[0] for _ in range(8)]
+    shards.drain(60)
+    rep.synchronize()
+    out = dict(losses=losses, psum=rep.arena.params.double().sum().item(), stats=vars(shards.stats),
+               versions=[board.shard_version(o) for o in range(world)])
+    shards.close()
+    comm.barrier()
+    comm.close()
+    return out
+
+
+def test_async_parameter_shards_in_hbm_over_ipc():
+    out = run_workers(_gpu_async_worker, 2, f"dtf_g_async_{os.getpid()}", timeout=300)
+    assert out[0]["versions"] == [16, 16]
+    assert sum(o["stats"]["applied"] for o in out) == 32
+    assert abs(out[0]["psum"] - out[1]["psum"]) < 1e-6 * max(1.0, abs(out[0]["psum"]))
+    assert out[0]["losses"][-1] < out[0]["losses"][0]
