@@ -64,7 +64,7 @@ PYBIND11_MODULE(_hip, m) {
     P(in, const float); P(wpk, const float); P(out, float);
     V(B); V(H); V(W); V(Cin); V(Ho); V(Wo); V(Cout);
     V(TH); V(TW); V(tiles_y); V(tiles_x);
-    V(pad); V(stride); V(upsample); V(nt_total);
+    V(pad); V(stride); V(upsample); V(nt_total); V(debug_skip);
     V(in_mode); a.in_bn = as_bn(d, "in_bn");
     V(res_mode); P(res, const float); a.res_bn = as_bn(d, "res_bn");
     V(epi_mode); P(bias, const float); P(mask_src, const float); a.mask_bn = as_bn(d, "mask_bn");

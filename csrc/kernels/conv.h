@@ -26,6 +26,7 @@ struct ConvFpropArgs {
   int stride;                    // 1 or 2 (must match the template instance)
   int upsample;                  // 1: `in` is read as if zero-upsampled by 2 (stride-2 dgrad)
   int nt_total;                  // 16-channel output tiles in the packed filter (= ceil(Cout/16))
+  int debug_skip;                // timing experiments only: 1 = no MFMA, 2 = no input loads, 4 = no epilogue memory traffic
   // prologue
   int in_mode;
   BnRef in_bn;

@@ -15,6 +15,8 @@
 // (or this BatchNorm's backward) needs, accumulated with fp64 atomics.
 #include "conv.h"
 
+#include <cstdlib>
+
 namespace dtf {
 
 namespace {
@@ -374,7 +376,22 @@ int choose_nt(const ConvFpropArgs& a, int ks, int cp, int s) {
                 : launch_fprop<KS_, S_, CP_, 1, 1>(a, stream);                            \
   }
 
+size_t conv_fprop_persist(const ConvFpropArgs& a_in, int ks, hipStream_t stream);
+
+static bool persist_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("DTF_CONV_PERSIST");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 size_t conv_fprop(const ConvFpropArgs& a_in, int ks, hipStream_t stream) {
+  // 3x3 ResNet shapes run on the persistent, software-pipelined kernel; everything else (and
+  // callers that pin a tiling) on the one-tile-per-block kernel below.
+  if (a_in.TH <= 0 && persist_enabled()) {
+    if (size_t r = conv_fprop_persist(a_in, ks, stream)) return r;
+  }
   ConvFpropArgs a = a_in;
   if (a.TH <= 0 || a.TW <= 0) conv_fprop_plan(a, ks);
   const int cp = pad_cin(a.Cin);

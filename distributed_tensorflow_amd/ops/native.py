@@ -138,6 +138,7 @@ def conv_fprop(
     extra: Optional[torch.Tensor] = None,
     out_sums: Optional[torch.Tensor] = None,
     out: Optional[torch.Tensor] = None,
+    debug_skip: int = 0,
 ) -> torch.Tensor:
     """Forward-shaped convolution with fused prologue/epilogues (see csrc/kernels/conv.h)."""
     require()
@@ -172,7 +173,7 @@ def conv_fprop(
         raise ValueError("conv_fprop: out has the wrong shape")
     d = dict(
         B=b, H=h, W=w_, Cin=cin, Ho=ho, Wo=wo, Cout=cout, pad=pad, stride=stride, upsample=int(upsample),
-        nt_total=nt_total, in_mode=IN_RAW, res_mode=res_mode, epi_mode=epi_mode,
+        nt_total=nt_total, in_mode=IN_RAW, res_mode=res_mode, epi_mode=epi_mode, debug_skip=debug_skip,
     )
     d["in"] = _chk(x, "x")
     d["wpk"] = _chk(wpk, "wpk")
