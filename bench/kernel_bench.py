@@ -50,7 +50,7 @@ def bn_for(x):
     c = x.shape[-1]
     flat = x.reshape(-1, c).double()
     sums = torch.cat([flat.sum(0), (flat * flat).sum(0)])
-    return nv.BnState(sums, torch.ones(c, device="cuda"), torch.zeros(c, device="cuda"), flat.shape[0])
+    return nv.BnState(nv.stats_from_totals(sums), torch.ones(c, device="cuda"), torch.zeros(c, device="cuda"), flat.shape[0])
 
 
 def main():
@@ -72,7 +72,7 @@ def main():
         wpk = nv.pack_weights(w)
         y = torch.empty(B, ho, ho, cout, device="cuda")
         dy = torch.randn(B, ho, ho, cout, device="cuda")
-        sums = torch.zeros(2 * cout, device="cuda", dtype=torch.float64)
+        sums = nv.new_stats(cout)
         flops = 2.0 * B * ho * ho * cout * 9 * cin
         bn = bn_for(x) if cin >= 16 else None
         res = torch.randn_like(y) if s == 1 and cin == cout else None
@@ -85,7 +85,7 @@ def main():
             wpk_t = nv.pack_weights(w, flip=True)
             _, pb, _ = same_pad(h, 3, s)
             dx = torch.empty_like(x)
-            gs = torch.zeros(2 * cin, device="cuda", dtype=torch.float64)
+            gs = nv.new_stats(cin)
             t = timeit(lambda: nv.conv_fprop(dy, wpk_t, ks=3, cout=cin, upsample=(s == 2), pad=2 - pb, out_hw=(h, h),
                                              epi_mode=nv.EPI_MASK, mask_src=x, mask_bn=bn, out_sums=gs, out=dx))
             byt = (dy.numel() + 2 * x.numel()) * 4
@@ -100,7 +100,7 @@ def main():
         g = torch.randn_like(x)
         r = torch.randn_like(x)
         bn = bn_for(x)
-        gs = torch.zeros(2 * c, device="cuda", dtype=torch.float64)
+        gs = nv.new_stats(c)
         out = torch.empty_like(x)
         t = timeit(lambda: nv.bn_bwd_apply(g, x, bn, gs, res_mode=nv.BWD_RES_IDENT, res=r, out=out))
         print(f"{f'{h}x{h}x{c}':>22s} {'bnbwd':>6s} {t:9.1f} {'':>9s} {4 * x.numel() * 4 / t / 1e3:10.0f}")

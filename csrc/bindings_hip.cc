@@ -68,7 +68,7 @@ PYBIND11_MODULE(_hip, m) {
     V(in_mode); a.in_bn = as_bn(d, "in_bn");
     V(res_mode); P(res, const float); a.res_bn = as_bn(d, "res_bn");
     V(epi_mode); P(bias, const float); P(mask_src, const float); a.mask_bn = as_bn(d, "mask_bn");
-    P(extra, const float); P(out_sums, double);
+    P(extra, const float); P(out_sums, double); P(dbg_stamps, unsigned long long);
     if (a.stride == 0) a.stride = 1;
     return conv_fprop(a, ks, as_stream(stream));
   });

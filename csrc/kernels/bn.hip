@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(BnStatsArgs a) {
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) atomicAdd(&a.sums[c], (double)red[c]);
+  double* slot = stat_slot(a.sums, C);
+  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) atomicAdd(&slot[c], (double)red[c]);
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
@@ -137,7 +138,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(BnReluBwdReduce
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) atomicAdd(&a.gsums[c], (double)red[c]);
+  double* slot = stat_slot(a.gsums, C);
+  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) atomicAdd(&slot[c], (double)red[c]);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdApplyArgs a) {
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdApplyArgs a) {
     float sc, shf;
     bn_coeffs(a.bn, c, C, sc, shf, mean[c], rstd[c]);
     k1[c] = sc;
-    const double sg = a.gsums[c], sgx = a.gsums[C + c];
+    const double sg = stat_total(a.gsums, c, C), sgx = stat_total(a.gsums, C + c, C);
     mg[c] = (float)(sg * (double)a.bn.inv_count);
     mgx[c] = (float)(sgx * (double)a.bn.inv_count);
     if (blockIdx.x == 0) {

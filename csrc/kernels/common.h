@@ -8,8 +8,12 @@
 //       A operand: lane l holds A[row = l & 15][k = l >> 4]
 //       B operand: lane l holds B[k = l >> 4][col = l & 15]
 //       C/D      : lane l, register r holds D[row = 4 * (l >> 4) + r][col = l & 15]
-//   * per-channel BatchNorm statistics travel as a block of 2*C doubles: sum then sum of
-//     squares, accumulated by the producing kernel's epilogue with fp64 atomics.
+//   * per-channel BatchNorm statistics travel as kStatSlots partial blocks of 2*C doubles (sum,
+//     then sum of squares), accumulated by the producing kernel's epilogue with fp64 atomics.
+//     A workgroup adds into slot (blockIdx.x % kStatSlots): workgroups are dealt round-robin to
+//     the 8 XCDs, so a slot's cache lines stay in one XCD's L2 and the atomics of different XCDs
+//     never contend for a line (one shared block costs ~10 us per kernel in serialised
+//     cross-die atomics). Consumers add the slots up.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,9 +24,23 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 namespace dtf {
 
+constexpr int kStatSlots = 8;
+
+// Total of statistic `idx` (0..2C-1) over the slots.
+__device__ __forceinline__ double stat_total(const double* sums, int idx, int C) {
+  double v[kStatSlots];
+#pragma unroll
+  for (int r = 0; r < kStatSlots; ++r) v[r] = sums[r * 2 * C + idx];
+  return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+// This workgroup's slot of a statistics block.
+__device__ __forceinline__ double* stat_slot(double* sums, int C) {
+  return sums + (size_t)(blockIdx.x & (kStatSlots - 1)) * 2 * C;
+}
+
 // Reference to one BatchNorm layer's batch statistics and affine parameters.
 struct BnRef {
-  const double* sums;   // [2*C]: per-channel sum, then per-channel sum of squares
+  const double* sums;   // [kStatSlots][2*C]: per-channel sum, then per-channel sum of squares
   const float* gamma;   // [C]
   const float* beta;    // [C]
   float inv_count;      // 1 / (B*H*W)
@@ -32,8 +50,8 @@ struct BnRef {
 // scale/shift such that bn(x) = x*scale + shift, plus mean/rstd for the backward pass.
 __device__ __forceinline__ void bn_coeffs(const BnRef& bn, int c, int C, float& scale, float& shift,
                                           float& mean_f, float& rstd_f) {
-  double mean = bn.sums[c] * (double)bn.inv_count;
-  double var = bn.sums[C + c] * (double)bn.inv_count - mean * mean;
+  double mean = stat_total(bn.sums, c, C) * (double)bn.inv_count;
+  double var = stat_total(bn.sums, C + c, C) * (double)bn.inv_count - mean * mean;
   if (var < 0.0) var = 0.0;
   float rstd = rsqrtf((float)var + bn.eps);
   float g = bn.gamma[c];

@@ -26,7 +26,8 @@ struct ConvFpropArgs {
   int stride;                    // 1 or 2 (must match the template instance)
   int upsample;                  // 1: `in` is read as if zero-upsampled by 2 (stride-2 dgrad)
   int nt_total;                  // 16-channel output tiles in the packed filter (= ceil(Cout/16))
-  int debug_skip;                // timing experiments only: 1 = no MFMA, 2 = no input loads, 4 = no epilogue memory traffic
+  int debug_skip;                // timing experiments only: 1 = no MFMA, 2 = no input loads, 4 = no epilogue memory traffic, 8 = no statistics flush
+  unsigned long long* dbg_stamps;  // timing experiments only: [blocks][16] wall-clock stamps of thread 0 (nullable)
   // prologue
   int in_mode;
   BnRef in_bn;
@@ -40,8 +41,8 @@ struct ConvFpropArgs {
   const float* mask_src;  // EPI_MASK: x such that the mask is bn(x) > 0, [B,Ho,Wo,Cout]
   BnRef mask_bn;
   const float* extra;     // EPI_MASK: optional gradient added before masking, [B,Ho,Wo,Cout]
-  // statistics accumulated over the written tensor (nullable): for forward the per-channel
-  // sum and sum of squares of `out`; for EPI_MASK the sums of g and g*xhat.
+  // statistics accumulated over the written tensor (nullable, [kStatSlots][2*Cout]): for forward
+  // the per-channel sum and sum of squares of `out`; for EPI_MASK the sums of g and g*xhat.
   double* out_sums;
 };
 

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(ConvFpropArgs a) {
       const int which = tid / (NT * 16);
       const int c = tid - which * (NT * 16);
       const int co = z * NT * 16 + c;
-      if (co < a.Cout) atomicAdd(&a.out_sums[which * a.Cout + co], (double)s_stat[tid]);
+      if (co < a.Cout) atomicAdd(&stat_slot(a.out_sums, a.Cout)[which * a.Cout + co], (double)s_stat[tid]);
     }
   }
 }

@@ -26,6 +26,8 @@ __global__ __launch_bounds__(256, (CP <= 16 && NT == 1) ? 3 : 2) void conv_fprop
   constexpr int KG = (CP >= 16) ? KS * KS * CG : (KS * KS + 3) / 4;
   constexpr int C4 = CP / 4;
 
+#define DTF_STAMP(k) do { if (a.dbg_stamps && threadIdx.x == 0) a.dbg_stamps[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+  DTF_STAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -48,6 +50,7 @@ __global__ __launch_bounds__(256, (CP <= 16 && NT == 1) ? 3 : 2) void conv_fprop
   float* s_w = s_in + round_up4(LH * LW * CPP);
   float* s_bn = s_w + KG * NT * 256;
   float* s_stat = s_bn + 2 * CP;
+  float* s_ebn = s_stat + 2 * NT * 16;
 
   // ---- prefetch registers for one input halo tile -------------------------------------------
   floatx4 pf[NPF];
@@ -134,26 +137,41 @@ __global__ __launch_bounds__(256, (CP <= 16 && NT == 1) ? 3 : 2) void conv_fprop
     }
   }
 
+  // Epilogue BatchNorm coefficients: computed once per block by NT*16 threads, handed to the
+  // lanes through LDS (every lane needs the four channels 4q..4q+3 of each of its N tiles).
+  if (tid < NT * 16) {
+    const int co = z * NT * 16 + tid;
+    float sc = 1.f, sh = 0.f, m = 0.f, r = 1.f, bias = 0.f;
+    if (co < a.Cout) {
+      if (a.res_mode == RES_BNRELU) bn_coeffs(a.res_bn, co, a.Cout, sc, sh, m, r);
+      if (a.epi_mode == EPI_MASK) bn_coeffs(a.mask_bn, co, a.Cout, sc, sh, m, r);
+      if (a.epi_mode == EPI_BIAS_RELU || a.epi_mode == EPI_BIAS) bias = a.bias[co];
+    }
+    s_ebn[tid] = sc;
+    s_ebn[NT * 16 + tid] = sh;
+    s_ebn[2 * NT * 16 + tid] = m;
+    s_ebn[3 * NT * 16 + tid] = r;
+    s_ebn[4 * NT * 16 + tid] = bias;
+  }
+  floatx4 st1[NT], st2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { st1[j] = floatx4{0.f, 0.f, 0.f, 0.f}; st2[j] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+  __syncthreads();   // s_bn / s_ebn ready
   float e_scale[NT][4], e_shift[NT][4], e_mean[NT][4], e_rstd[NT][4], e_bias[NT][4];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int co = (z * NT + j) * 16 + 4 * q + r;
-      e_scale[j][r] = 1.f; e_shift[j][r] = 0.f; e_mean[j][r] = 0.f; e_rstd[j][r] = 1.f; e_bias[j][r] = 0.f;
-      if (co < a.Cout) {
-        if (a.res_mode == RES_BNRELU)
-          bn_coeffs(a.res_bn, co, a.Cout, e_scale[j][r], e_shift[j][r], e_mean[j][r], e_rstd[j][r]);
-        if (a.epi_mode == EPI_MASK)
-          bn_coeffs(a.mask_bn, co, a.Cout, e_scale[j][r], e_shift[j][r], e_mean[j][r], e_rstd[j][r]);
-        if (a.epi_mode == EPI_BIAS_RELU || a.epi_mode == EPI_BIAS) e_bias[j][r] = a.bias[co];
-      }
+      const int c = j * 16 + 4 * q + r;
+      e_scale[j][r] = s_ebn[c];
+      e_shift[j][r] = s_ebn[NT * 16 + c];
+      e_mean[j][r] = s_ebn[2 * NT * 16 + c];
+      e_rstd[j][r] = s_ebn[3 * NT * 16 + c];
+      e_bias[j][r] = s_ebn[4 * NT * 16 + c];
     }
   }
-  floatx4 st1[NT], st2[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) { st1[j] = floatx4{0.f, 0.f, 0.f, 0.f}; st2[j] = floatx4{0.f, 0.f, 0.f, 0.f}; }
-  __syncthreads();   // s_bn ready for write_tile
+  DTF_STAMP(1);
+  int it = 0;
 
   const int tile_px = a.TH * a.TW;
   const int n_mt = (tile_px + 15) >> 4;
@@ -168,6 +186,7 @@ __global__ __launch_bounds__(256, (CP <= 16 && NT == 1) ? 3 : 2) void conv_fprop
 
     write_tile();
     __syncthreads();
+    if (it < 3) DTF_STAMP(2 + 4 * it);
     if (t + gpz < total_tiles) load_tile(t + gpz);   // in flight during the MFMA phase
 
     for (int mb = wave * MTW; mb < n_mt; mb += 4 * MTW) {
@@ -203,6 +222,7 @@ __global__ __launch_bounds__(256, (CP <= 16 && NT == 1) ? 3 : 2) void conv_fprop
         }
       }
 
+      if (it < 3 && mb == wave * MTW) DTF_STAMP(3 + 4 * it);
       if (!(a.debug_skip & 1)) {
       if constexpr (CP >= 16) {
 #pragma unroll
@@ -249,6 +269,7 @@ __global__ __launch_bounds__(256, (CP <= 16 && NT == 1) ? 3 : 2) void conv_fprop
         }
       }
       }
+      if (it < 3 && mb == wave * MTW) DTF_STAMP(4 + 4 * it);
 
 #pragma unroll
       for (int i = 0; i < MTW; ++i) {
@@ -303,9 +324,12 @@ __global__ __launch_bounds__(256, (CP <= 16 && NT == 1) ? 3 : 2) void conv_fprop
       }
     }
     __syncthreads();   // all waves are done reading s_in before the next tile overwrites it
+    if (it < 3) DTF_STAMP(5 + 4 * it);
+    ++it;
   }
 
-  if (a.out_sums) {
+  DTF_STAMP(14);
+  if (a.out_sums && !(a.debug_skip & 8)) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
 #pragma unroll
@@ -327,16 +351,18 @@ __global__ __launch_bounds__(256, (CP <= 16 && NT == 1) ? 3 : 2) void conv_fprop
       const int which = tid / (NT * 16);
       const int c = tid - which * (NT * 16);
       const int co = z * NT * 16 + c;
-      if (co < a.Cout) atomicAdd(&a.out_sums[which * a.Cout + co], (double)s_stat[tid]);
+      if (co < a.Cout) atomicAdd(&stat_slot(a.out_sums, a.Cout)[which * a.Cout + co], (double)s_stat[tid]);
     }
   }
+  DTF_STAMP(15);
+#undef DTF_STAMP
 }
 
 size_t lds_bytes_p(int ks, int s, int cp, int nt, int th, int tw) {
   const int cpp = cp + 4;
   const int kg = (cp >= 16) ? ks * ks * (cp / 16) : (ks * ks + 3) / 4;
   const int lh = (th - 1) * s + ks, lw = (tw - 1) * s + ks;
-  return ((size_t)((lh * lw * cpp + 3) & ~3) + (size_t)kg * nt * 256 + 2 * cp + 2 * nt * 16) * 4;
+  return ((size_t)((lh * lw * cpp + 3) & ~3) + (size_t)kg * nt * 256 + 2 * cp + 7 * nt * 16) * 4;
 }
 
 template <int KS, int S, int CP, int NT, int MTW, int NPF>

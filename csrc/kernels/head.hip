@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
     atomicAdd(&s_red[C + c + e], s2[e]);
   }
   __syncthreads();
-  for (int cc = tid; cc < 2 * C; cc += 256) atomicAdd(&a.gsums[cc], (double)s_red[cc]);
+  double* slot = stat_slot(a.gsums, C);
+  for (int cc = tid; cc < 2 * C; cc += 256) atomicAdd(&slot[cc], (double)s_red[cc]);
 }
 
 // FC parameter gradients: one thread per (c, k) element walks the batch; dW[c][k] = sum_n

@@ -10,7 +10,7 @@ namespace dtf {
 // tf.nn.batch_normalization; no moving averages).
 struct BnStatsArgs {
   const float* x;   // [N, C] flattened NHWC
-  double* sums;     // [2*C] += sum, sum of squares
+  double* sums;     // [kStatSlots][2*C] += sum, sum of squares
   long long n_rows;
   int C;
 };
@@ -33,7 +33,7 @@ struct BnReluBwdReduceArgs {
   const float* x;
   float* g;         // may alias dy
   BnRef bn;
-  double* gsums;    // [2*C] += sum g, sum g*xhat
+  double* gsums;    // [kStatSlots][2*C] += sum g, sum g*xhat
   long long n_rows;
   int C;
   int relu;         // 0: no mask (plain BatchNorm)
@@ -48,7 +48,7 @@ struct BnBwdApplyArgs {
   const float* x;
   float* dx;            // may alias g
   BnRef bn;
-  const double* gsums;  // [2*C]
+  const double* gsums;  // [kStatSlots][2*C]
   float* dgamma;        // nullable
   float* dbeta;         // nullable
   long long n_rows;
@@ -83,7 +83,7 @@ struct HeadBwdArgs {
   const float* feat;     // [B, C]
   const float* dlogits;  // [B, K]
   float* g;              // [B, HW, C]  masked gradient wrt bn output
-  double* gsums;         // [2*C] += sum g, sum g*xhat
+  double* gsums;         // [kStatSlots][2*C] += sum g, sum g*xhat
   float* d_fc_w;         // [C, K] +=
   float* d_fc_b;         // [K] +=
   int B, HW, C, K;

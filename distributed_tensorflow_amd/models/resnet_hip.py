@@ -43,7 +43,7 @@ PACK_DTYPE = np.dtype(
 @dataclass
 class _Bn:
     fwd: nv.BnState        # statistics of the BN input tensor
-    gsums: torch.Tensor    # float64 [2C] backward reductions
+    gsums: torch.Tensor    # float64 statistics block of the backward reductions
     gamma_name: str
     beta_name: str
 
@@ -86,7 +86,7 @@ class ResNetHipStep(StepProgramBase):
 
         # ---- BatchNorm statistics arena (fp64), zeroed once per step
         bn_channels = [16] + [c for blk in self.blocks for c in (([] if blk.first_block else [blk.conv1.cin]) + [blk.conv2.cin])] + [64]
-        self.stats = torch.zeros(sum(4 * c for c in bn_channels), device=dev, dtype=torch.float64)
+        self.stats = torch.zeros(sum(2 * nv.STAT_SLOTS * 2 * c for c in bn_channels), device=dev, dtype=torch.float64)
         self._stat_off = 0
         a = arena
         self.bn0 = self._make_bn(16, B * 32 * 32, "conv0/gamma", "conv0/beta")
@@ -139,10 +139,10 @@ class ResNetHipStep(StepProgramBase):
 
     # ------------------------------------------------------------------------------------------
     def _make_bn(self, c: int, count: int, gamma: str, beta: str) -> _Bn:
-        o = self._stat_off
-        self._stat_off += 4 * c
-        st = nv.BnState(self.stats[o:o + 2 * c], self.arena.param(gamma), self.arena.param(beta), count, BN_EPSILON)
-        return _Bn(st, self.stats[o + 2 * c:o + 4 * c], gamma, beta)
+        o, n = self._stat_off, nv.STAT_SLOTS * 2 * c
+        self._stat_off += 2 * n
+        st = nv.BnState(self.stats[o:o + n], self.arena.param(gamma), self.arena.param(beta), count, BN_EPSILON)
+        return _Bn(st, self.stats[o + n:o + 2 * n], gamma, beta)
 
     def _wpk(self, name: str, bwd: bool = False) -> torch.Tensor:
         off, n = (self._pk_bwd if bwd else self._pk_fwd)[name]

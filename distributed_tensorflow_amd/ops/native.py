@@ -65,11 +65,33 @@ def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
     return t.data_ptr()
 
 
+# A statistics block is STAT_SLOTS partial blocks of 2*C doubles; kernels add into the slot of
+# their workgroup's XCD and consumers add the slots up (see csrc/kernels/common.h).
+STAT_SLOTS = 8
+
+
+def new_stats(c: int, device="cuda") -> torch.Tensor:
+    """Zeroed statistics block for C channels."""
+    return torch.zeros(STAT_SLOTS * 2 * c, device=device, dtype=torch.float64)
+
+
+def stats_from_totals(totals: torch.Tensor) -> torch.Tensor:
+    """Statistics block whose slots add up to `totals` ([2*C] float64)."""
+    out = torch.zeros(STAT_SLOTS * totals.numel(), device=totals.device, dtype=torch.float64)
+    out[: totals.numel()] = totals
+    return out
+
+
+def stats_total(sums: torch.Tensor) -> torch.Tensor:
+    """[2*C] totals of a statistics block."""
+    return sums.view(STAT_SLOTS, -1).sum(0)
+
+
 @dataclass
 class BnState:
     """Batch statistics (fp64 sum / sum of squares) plus affine parameters of one BN layer."""
 
-    sums: torch.Tensor   # float64 [2*C]
+    sums: torch.Tensor   # float64 [STAT_SLOTS * 2*C]
     gamma: torch.Tensor  # float32 [C]
     beta: torch.Tensor   # float32 [C]
     count: int           # B*H*W the statistics are taken over
@@ -77,8 +99,8 @@ class BnState:
 
     def ref(self):
         c = self.gamma.numel()
-        if self.sums.dtype != torch.float64 or self.sums.numel() != 2 * c:
-            raise ValueError("BnState.sums must be float64 [2*C]")
+        if self.sums.dtype != torch.float64 or self.sums.numel() != STAT_SLOTS * 2 * c:
+            raise ValueError("BnState.sums must be float64 [STAT_SLOTS*2*C]")
         if self.beta.numel() != c:
             raise ValueError("BnState gamma/beta size mismatch")
         for t in (self.sums, self.gamma, self.beta):
@@ -139,6 +161,7 @@ def conv_fprop(
     out_sums: Optional[torch.Tensor] = None,
     out: Optional[torch.Tensor] = None,
     debug_skip: int = 0,
+    dbg_stamps: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """Forward-shaped convolution with fused prologue/epilogues (see csrc/kernels/conv.h)."""
     require()
@@ -209,9 +232,11 @@ def conv_fprop(
                 raise ValueError("extra must match the output shape")
             d["extra"] = _chk(extra, "extra")
     if out_sums is not None:
-        if out_sums.numel() != 2 * cout:
-            raise ValueError("out_sums must be [2*Cout]")
+        if out_sums.numel() != STAT_SLOTS * 2 * cout:
+            raise ValueError("out_sums must be [STAT_SLOTS*2*Cout]")
         d["out_sums"] = _chk(out_sums, "out_sums", torch.float64)
+    if dbg_stamps is not None:
+        d["dbg_stamps"] = _chk(dbg_stamps, "dbg_stamps", torch.int64)
     hip().conv_fprop(d, ks, stream())
     return out
 
@@ -253,7 +278,7 @@ def bn_stats(x: torch.Tensor, sums: Optional[torch.Tensor] = None) -> torch.Tens
     require()
     c = x.shape[-1]
     if sums is None:
-        sums = torch.zeros(2 * c, device=x.device, dtype=torch.float64)
+        sums = new_stats(c, x.device)
     hip().bn_stats(dict(x=_chk(x, "x"), sums=_chk(sums, "sums", torch.float64), n_rows=x.numel() // c, C=c), stream())
     return sums
 
@@ -272,7 +297,7 @@ def bn_apply(x: torch.Tensor, bn: BnState, relu: bool = True, out: Optional[torc
 def bn_relu_bwd_reduce(dy, x, bn: BnState, gsums, relu=True, out=None):
     require()
     c = x.shape[-1]
-    if dy.shape != x.shape or bn.channels != c or gsums.numel() != 2 * c:
+    if dy.shape != x.shape or bn.channels != c or gsums.numel() != STAT_SLOTS * 2 * c:
         raise ValueError("bn_relu_bwd_reduce: shape mismatch")
     if out is None:
         out = torch.empty_like(dy)
@@ -285,7 +310,7 @@ def bn_relu_bwd_reduce(dy, x, bn: BnState, gsums, relu=True, out=None):
 def bn_bwd_apply(g, x, bn: BnState, gsums, *, dgamma=None, dbeta=None, res_mode=BWD_RES_NONE, res=None, out=None):
     require()
     c = x.shape[-1]
-    if g.shape != x.shape or bn.channels != c or gsums.numel() != 2 * c:
+    if g.shape != x.shape or bn.channels != c or gsums.numel() != STAT_SLOTS * 2 * c:
         raise ValueError("bn_bwd_apply: shape mismatch")
     if out is None:
         out = torch.empty_like(g)
@@ -331,7 +356,7 @@ def head_bwd(x, bn: BnState, fc_w, feat, dlogits, g, gsums, d_fc_w, d_fc_b):
     require()
     b, h, w_, c = x.shape
     k = fc_w.shape[1]
-    if g.shape != x.shape or tuple(d_fc_w.shape) != (c, k) or d_fc_b.numel() != k or gsums.numel() != 2 * c:
+    if g.shape != x.shape or tuple(d_fc_w.shape) != (c, k) or d_fc_b.numel() != k or gsums.numel() != STAT_SLOTS * 2 * c:
         raise ValueError("head_bwd: shape mismatch")
     if tuple(feat.shape) != (b, c) or tuple(dlogits.shape) != (b, k):
         raise ValueError("head_bwd: saved tensor shape mismatch")

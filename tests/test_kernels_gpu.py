@@ -34,7 +34,7 @@ def bn_state_for(x, gamma, beta):
     c = x.shape[-1]
     flat = x.reshape(-1, c).double()
     sums = torch.cat([flat.sum(0), (flat * flat).sum(0)]).to(DEV)
-    return nv.BnState(sums, gamma, beta, flat.shape[0])
+    return nv.BnState(nv.stats_from_totals(sums), gamma, beta, flat.shape[0])
 
 
 CONV_CASES = [
@@ -70,12 +70,13 @@ def test_conv_fprop_bn_prologue_and_stats(case):
     wt = rnd(ks, ks, cin, cout, scale=0.1)
     a = torch.relu(ref.batch_norm(x, gamma, beta))
     want = ref.conv2d_same(a, wt, s)
-    sums = torch.zeros(2 * cout, device=DEV, dtype=torch.float64)
+    sums = nv.new_stats(cout, DEV)
     got = nv.conv_fprop(x, nv.pack_weights(wt), ks=ks, cout=cout, stride=s, in_bn=bn_state_for(x, gamma, beta), out_sums=sums)
     close(got, want)
     flat = want.reshape(-1, cout).double()
-    close(sums[:cout], flat.sum(0), 1e-5)
-    close(sums[cout:], (flat * flat).sum(0), 1e-5)
+    tot = nv.stats_total(sums)
+    close(tot[:cout], flat.sum(0), 1e-5)
+    close(tot[cout:], (flat * flat).sum(0), 1e-5)
 
 
 def test_conv_fprop_residual_modes():
@@ -130,14 +131,15 @@ def test_conv_dgrad_mask_epilogue():
     bnv = ref.batch_norm(x_pre, gamma, beta)
     want = torch.where(bnv > 0, da + extra, torch.zeros_like(da))
     st = bn_state_for(x_pre, gamma, beta)
-    gs = torch.zeros(2 * cin, device=DEV, dtype=torch.float64)
+    gs = nv.new_stats(cin, DEV)
     got = nv.conv_fprop(dy, nv.pack_weights(wt, flip=True), ks=3, cout=cin, pad=1, out_hw=(h, w),
                         epi_mode=nv.EPI_MASK, mask_src=x_pre, mask_bn=st, extra=extra, out_sums=gs)
     close(got, want)
     mean, var = ref.batch_moments(x_pre)
     xhat = (x_pre - mean) * torch.rsqrt(var + ref.BN_EPSILON)
-    close(gs[:cin], want.reshape(-1, cin).double().sum(0), 1e-4)
-    close(gs[cin:], (want * xhat).reshape(-1, cin).double().sum(0), 1e-4)
+    gt = nv.stats_total(gs)
+    close(gt[:cin], want.reshape(-1, cin).double().sum(0), 1e-4)
+    close(gt[cin:], (want * xhat).reshape(-1, cin).double().sum(0), 1e-4)
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
@@ -177,8 +179,9 @@ def test_bn_stats_apply_and_backward():
     gamma, beta = rnd(c).abs() + 0.5, rnd(c, scale=0.3)
     sums = nv.bn_stats(x)
     flat = x.reshape(-1, c).double()
-    close(sums[:c], flat.sum(0), 1e-6)
-    close(sums[c:], (flat * flat).sum(0), 1e-6)
+    tot = nv.stats_total(sums)
+    close(tot[:c], flat.sum(0), 1e-6)
+    close(tot[c:], (flat * flat).sum(0), 1e-6)
     st = nv.BnState(sums, gamma, beta, flat.shape[0])
     close(nv.bn_apply(x, st, relu=True), torch.relu(ref.batch_norm(x, gamma, beta)))
     close(nv.bn_apply(x, st, relu=False), ref.batch_norm(x, gamma, beta))
@@ -188,7 +191,7 @@ def test_bn_stats_apply_and_backward():
     y = torch.relu(ref.batch_norm(xr, gr, br))
     dy = rnd(*x.shape, seed=23)
     dx_want, dg_want, db_want = torch.autograd.grad(y, (xr, gr, br), dy)
-    gs = torch.zeros(2 * c, device=DEV, dtype=torch.float64)
+    gs = nv.new_stats(c, DEV)
     g = nv.bn_relu_bwd_reduce(dy, x, st, gs, relu=True)
     dgamma, dbeta = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
     res = rnd(*x.shape, seed=29)
@@ -206,7 +209,7 @@ def test_bn_bwd_apply_shortcut_a():
     dy_block = rnd(b, h // 2, w // 2, 2 * c, seed=31)
     xs = x.clone().requires_grad_(True)
     (want_sc,) = torch.autograd.grad(ref.shortcut_a(xs), xs, dy_block)
-    gs = torch.zeros(2 * c, device=DEV, dtype=torch.float64)
+    gs = nv.new_stats(c, DEV)
     g = nv.bn_relu_bwd_reduce(torch.zeros_like(x), x, st, gs)
     dx = nv.bn_bwd_apply(g, x, st, gs, res_mode=nv.BWD_RES_SHORTCUT_A, res=dy_block)
     close(dx, want_sc)
@@ -240,7 +243,7 @@ def test_head_fwd_bwd():
     assert int(correct.item()) == ref.top1_hits(logits_ref, labels)
 
     g = torch.empty_like(x)
-    gs = torch.zeros(2 * c, device=DEV, dtype=torch.float64)
+    gs = nv.new_stats(c, DEV)
     d_w, d_b = torch.zeros_like(fc_w), torch.zeros_like(fc_b)
     nv.head_bwd(x, st, fc_w, feat, dlogits, g, gs, d_w, d_b)
     dgamma, dbeta = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
