@@ -83,7 +83,7 @@ PYBIND11_MODULE(_hip, m) {
     V(B); V(H); V(W); V(Cin); V(Ho); V(Wo); V(Cout);
     V(TH); V(TW); V(tiles_y); V(tiles_x);
     V(pad); V(stride); V(in_mode); a.in_bn = as_bn(d, "in_bn");
-    V(tiles_per_block);
+    V(tiles_per_block); V(dw_slot_stride); V(co_tiles); V(debug_skip); P(dbg_stamps, unsigned long long);
     if (a.stride == 0) a.stride = 1;
     return conv_wgrad(a, ks, as_stream(stream));
   });
@@ -165,6 +165,11 @@ PYBIND11_MODULE(_hip, m) {
     AxpyArgs a{};
     P(y, float); P(x, const float); V(alpha); V(n);
     flat_axpy(a, as_stream(stream));
+  });
+  m.def("slot_reduce", [](const py::dict& d, uint64_t stream) {
+    SlotReduceArgs a{};
+    P(y, float); P(slots, float); V(n); V(slot_stride);
+    slot_reduce(a, as_stream(stream));
   });
   m.def("memset", [](uint64_t dst, int value, uint64_t bytes, uint64_t stream) {
     memset_async(reinterpret_cast<void*>(dst), value, bytes, as_stream(stream));

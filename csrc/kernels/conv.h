@@ -65,7 +65,9 @@ void pack_conv_weights(const PackArgs& a, hipStream_t stream);
 size_t packed_weight_floats(int ks, int Cin, int Cout, int transpose_flip);
 
 // Filter gradient: dW[kh,kw,ci,co] += sum_{n,y,x} act(in)[n, y*s+kh-pad, x*s+kw-pad, ci] * dout[n,y,x,co]
-// accumulated with fp32 atomics into `dw` (HWIO), which the caller zeroes beforehand.
+// accumulated with fp32 atomics into `dw` (HWIO), which the caller zeroes beforehand. With
+// `dw_slot_stride` > 0 a workgroup adds into the copy dw + (blockIdx.x % kStatSlots) * stride, so
+// the atomics of one XCD never leave its L2; the caller sums the kStatSlots copies afterwards.
 struct ConvWgradArgs {
   const float* in;     // [B,H,W,Cin]
   const float* dout;   // [B,Ho,Wo,Cout]
@@ -78,7 +80,13 @@ struct ConvWgradArgs {
   BnRef in_bn;
   int tiles_per_block;   // tiles of the flattened (image, tile) sequence walked by one block
   float* dbias;          // nullable: [Cout] += sum of dout (LeNet bias gradient)
+  long long dw_slot_stride;  // floats between the per-XCD copies of dw (0: one copy)
+  int co_tiles;          // 16-channel output tiles per block (0: chosen by the launcher)
+  int debug_skip;        // timing experiments only: 1 = no MFMA, 2 = no loads, 4 = no flush
+  unsigned long long* dbg_stamps;  // timing experiments only: [blocks][16] wall-clock stamps of thread 0
 };
 size_t conv_wgrad(ConvWgradArgs a, int ks, hipStream_t stream);
+// Band-tiled persistent variant for the 3x3 ResNet shapes; returns 0 when the shape is not covered.
+size_t conv_wgrad_band(const ConvWgradArgs& a, int ks, hipStream_t stream);
 
 }  // namespace dtf

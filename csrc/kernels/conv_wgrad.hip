@@ -12,6 +12,8 @@
 //  DistributedResNet/src/distributed_train.py:256)
 #include "conv.h"
 
+#include <cstdlib>
+
 namespace dtf {
 namespace {
 
@@ -19,6 +21,8 @@ __device__ __forceinline__ int round_up4(int v) { return (v + 3) & ~3; }
 
 template <int KS, int S, int CP, int CO_T>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
+#define DTF_STAMP(k) do { if (a.dbg_stamps && threadIdx.x == 0) a.dbg_stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = wall_clock64(); } while (0)
+  DTF_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int CPP = CP + 4;
   constexpr int CO_B = CO_T * 16;
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
         const int r = pix / LW;
         const int c = pix - r * LW;
         const int iy = vy0 + r, ix = vx0 + c;
-        const bool ok = (iy >= 0) && (ix >= 0) && (iy < a.H) && (ix < a.W);
+        const bool ok = (iy >= 0) && (ix >= 0) && (iy < a.H) && (ix < a.W) && !(a.debug_skip & 2);
         floatx4 v = {0.f, 0.f, 0.f, 0.f};
         if (ok) {
           const float* src = a.in + ((size_t)(n * a.H + iy) * a.W + ix) * a.Cin + c4 * 4;
@@ -122,15 +126,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
         const int oy = oy0 + ty, ox = ox0 + tx;
         floatx4 v = {0.f, 0.f, 0.f, 0.f};
         const int co = co_blk0 + c4 * 4;
-        if (p < tile_px && oy < a.Ho && ox < a.Wo && co < a.Cout)
+        if (p < tile_px && oy < a.Ho && ox < a.Wo && co < a.Cout && !(a.debug_skip & 2))
           v = *reinterpret_cast<const floatx4*>(a.dout + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + co);
         *reinterpret_cast<floatx4*>(s_do + p * COP + c4 * 4) = v;
       }
     }
     __syncthreads();
+    if (t == t_begin) DTF_STAMP(1);
 
     // ---- accumulate: k-steps of four pixels ----
     const int n_steps = px_pad >> 2;
+    if (!(a.debug_skip & 1))
     for (int step = wx; step < n_steps; step += WX) {
       int p = step * 4 + q;
       const int pc = p < tile_px ? p : 0;
@@ -169,8 +175,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
         }
       }
     }
+    if (t == t_begin) DTF_STAMP(2);
   }
+  DTF_STAMP(3);
 
+  if (a.debug_skip & 4) return;
+  float* dw = a.dw + (size_t)(blockIdx.x & (kStatSlots - 1)) * a.dw_slot_stride;
   // ---- flush: per tap, gather the block's [CI_T*16][CO_B] slab in LDS, then coalesced atomics
 #pragma unroll
   for (int tap = 0; tap < TAPS; ++tap) {  // unrolled: acc[][] must be indexed statically
@@ -207,10 +217,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
       }
       if (tap_g < KS * KS && ci < a.Cin && co < a.Cout) {
         const float v = s_red[i];
-        if (v != 0.f) atomicAdd(a.dw + ((size_t)tap_g * a.Cin + ci) * a.Cout + co, v);
+        if (v != 0.f) atomicAdd(dw + ((size_t)tap_g * a.Cin + ci) * a.Cout + co, v);
       }
     }
+    if (tap < 9) DTF_STAMP(4 + tap);
   }
+  DTF_STAMP(15);
+#undef DTF_STAMP
 }
 
 template <int KS, int S, int CP, int CO_T>
@@ -241,6 +254,13 @@ size_t launch_wgrad(const ConvWgradArgs& a, hipStream_t stream) {
   }
 
 size_t conv_wgrad(ConvWgradArgs a, int ks, hipStream_t stream) {
+  static const bool use_band = [] {
+    const char* e = getenv("DTF_WGRAD_BAND");
+    return !(e && e[0] == '0');
+  }();
+  if (use_band && a.TH <= 0) {
+    if (const size_t r = conv_wgrad_band(a, ks, stream)) return r;
+  }
   int cp;
   if (a.Cin <= 4) cp = 4;
   else if (a.Cin <= 16) cp = 16;
@@ -260,6 +280,11 @@ size_t conv_wgrad(ConvWgradArgs a, int ks, hipStream_t stream) {
   const int ci_t = cp >= 16 ? cp / 16 : (ks * ks + 3) / 4;
   const int taps = cp >= 16 ? ks * ks : 1;
   int co_t = 1;
+  if (a.co_tiles > 0) {
+    if (nt_total % a.co_tiles || (a.co_tiles != 1 && a.co_tiles != 2 && a.co_tiles != 4))
+      throw std::runtime_error("conv_wgrad: co_tiles must be 1, 2 or 4 and divide the output tiles");
+    co_t = a.co_tiles;
+  } else
   for (int cand : {4, 2}) {
     if (nt_total % cand) continue;
     const int pairs = ci_t * cand;

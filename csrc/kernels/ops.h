@@ -123,6 +123,11 @@ void flat_scale(const FlatScaleArgs& a, hipStream_t stream);   // x *= (scale_de
 struct AxpyArgs { float* y; const float* x; float alpha; long long n; };
 void flat_axpy(const AxpyArgs& a, hipStream_t stream);         // y += alpha*x
 
+// y[0:n] += sum of the kStatSlots copies slots[r*slot_stride + (0:n)] (per-XCD filter-gradient
+// copies, see ConvWgradArgs::dw_slot_stride); the copies are zeroed where they held anything.
+struct SlotReduceArgs { float* y; float* slots; long long n; long long slot_stride; };
+void slot_reduce(const SlotReduceArgs& a, hipStream_t stream);
+
 struct AddReluArgs { const float* a; const float* b; float* out; long long n; int relu_first; };
 void add_relu_fwd(const AddReluArgs& a, hipStream_t stream);   // relu_first ? relu(a)+b : relu(a+b)
 struct AddReluBwdArgs { const float* dout; const float* a; const float* b; float* da; float* db; long long n; int relu_first; };

@@ -100,7 +100,44 @@ __global__ __launch_bounds__(256) void axpy_kernel(AxpyArgs a) {
   if (gi < a.n - tail0) a.y[tail0 + gi] += a.alpha * a.x[tail0 + gi];
 }
 
+// y[i] += sum over the kStatSlots copies of x; the copies are cleared for the next step.
+__global__ __launch_bounds__(256) void slot_reduce_kernel(SlotReduceArgs a) {
+  const long long n4 = a.n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  floatx4* y4 = reinterpret_cast<floatx4*>(a.y);
+  const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long long i = gi; i < n4; i += stride) {
+    floatx4 v[kStatSlots];
+#pragma unroll
+    for (int r = 0; r < kStatSlots; ++r) v[r] = *reinterpret_cast<const floatx4*>(a.slots + r * a.slot_stride + 4 * i);
+    floatx4 s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) any = any || (s[e] != 0.f);
+    if (any) {
+      y4[i] = y4[i] + s;
+#pragma unroll
+      for (int r = 0; r < kStatSlots; ++r)
+        *reinterpret_cast<floatx4*>(a.slots + r * a.slot_stride + 4 * i) = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const long long tail0 = n4 << 2;
+  if (gi < a.n - tail0) {
+    float s = 0.f;
+    for (int r = 0; r < kStatSlots; ++r) {
+      s += a.slots[r * a.slot_stride + tail0 + gi];
+      a.slots[r * a.slot_stride + tail0 + gi] = 0.f;
+    }
+    a.y[tail0 + gi] += s;
+  }
+}
+
 }  // namespace
+
+void slot_reduce(const SlotReduceArgs& a, hipStream_t stream) {
+  if ((a.slot_stride & 3) != 0) throw std::runtime_error("slot_reduce: slot stride must be a multiple of 4 floats");
+  launch("slot_reduce", slot_reduce_kernel, dim3(flat_blocks(a.n >> 2)), dim3(256), 0, stream, a);
+}
 
 void fused_adam(const FlatOptArgs& a, hipStream_t stream) {
   launch("fused_adam", adam_kernel, dim3(flat_blocks(a.n >> 2)), dim3(256), 0, stream, a);

@@ -133,6 +133,9 @@ class ResNetHipStep(StepProgramBase):
         if training:
             big = B * 32 * 32 * 16
             self._gbuf = [torch.empty(big, **f32) for _ in range(3)]
+            # per-XCD copies of the filter gradients (see ConvWgradArgs::dw_slot_stride), summed into
+            # the gradient arena at the end of every bucket segment
+            self._wslots = torch.zeros(nv.STAT_SLOTS, arena.total, **f32)
 
         self._record(num_buckets)
         self.set_hyper(lr_t=0.0)
@@ -143,6 +146,12 @@ class ResNetHipStep(StepProgramBase):
         self._stat_off += 2 * n
         st = nv.BnState(self.stats[o:o + n], self.arena.param(gamma), self.arena.param(beta), count, BN_EPSILON)
         return _Bn(st, self.stats[o + n:o + 2 * n], gamma, beta)
+
+    def _wgrad(self, x: torch.Tensor, dout: torch.Tensor, name: str, stride: int, in_bn=None) -> None:
+        a = self.arena
+        off, spec = a.offsets[name], a.spec(name)
+        dw = self._wslots[0, off:off + spec.numel].view(spec.shape)
+        nv.conv_wgrad(x, dout, dw, stride=stride, in_bn=in_bn, slot_stride=a.total)
 
     def _wpk(self, name: str, bwd: bool = False) -> torch.Tensor:
         off, n = (self._pk_bwd if bwd else self._pk_fwd)[name]
@@ -215,14 +224,14 @@ class ResNetHipStep(StepProgramBase):
             c1 = self.c1[k]
             dy = self._view(bufs[0], self.y[k].shape)
             # conv2: filter gradient, masked data gradient, BN backward
-            nv.conv_wgrad(c1, dy, a.grad(blk.conv2.weight), stride=1, in_bn=bn2.fwd)
+            self._wgrad(c1, dy, blk.conv2.weight, 1, bn2.fwd)
             g2 = nv.conv_fprop(dy, self._wpk(blk.conv2.weight, True), ks=3, cout=blk.conv2.cin, pad=1,
                                out_hw=(c1.shape[1], c1.shape[2]), epi_mode=nv.EPI_MASK, mask_src=c1, mask_bn=bn2.fwd,
                                out_sums=bn2.gsums, out=self._view(bufs[1], c1.shape))
             dc1 = nv.bn_bwd_apply(g2, c1, bn2.fwd, bn2.gsums, dgamma=a.grad(bn2.gamma_name), dbeta=a.grad(bn2.beta_name), out=g2)
             # conv1
             s = blk.conv1.stride
-            nv.conv_wgrad(x_in, dc1, a.grad(blk.conv1.weight), stride=s, in_bn=bn1.fwd)
+            self._wgrad(x_in, dc1, blk.conv1.weight, s, bn1.fwd)
             _, pb, _ = same_pad(x_in.shape[1], 3, s)
             g1 = nv.conv_fprop(dc1, self._wpk(blk.conv1.weight, True), ks=3, cout=blk.conv1.cin, stride=1,
                                upsample=(s == 2), pad=2 - pb, out_hw=(x_in.shape[1], x_in.shape[2]),
@@ -239,12 +248,14 @@ class ResNetHipStep(StepProgramBase):
                             out=g1, **res)
             bufs = [bufs[2], bufs[1], bufs[0]]
             if k in marks:
+                nv.slot_reduce(a.grads, self._wslots, marks[k], hi)
                 self.bucket_ranges.append((marks[k], hi))
                 hi = marks[k]
                 self.program.mark_segment()
         # stem: filter gradient of conv0 from the raw images
         dc0 = self._view(bufs[0], self.c0.shape)
-        nv.conv_wgrad(self.images, dc0, a.grad("conv0/conv"), stride=1)
+        self._wgrad(self.images, dc0, "conv0/conv", 1)
+        nv.slot_reduce(a.grads, self._wslots, 0, hi)
         self.bucket_ranges.append((0, hi))
         self.program.mark_segment()
 

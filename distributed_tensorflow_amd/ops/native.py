@@ -249,8 +249,15 @@ def conv_wgrad(
     stride: int = 1,
     in_bn: Optional[BnState] = None,
     tiles_per_block: int = 0,
+    slot_stride: int = 0,
+    co_tiles: int = 0,
+    debug_skip: int = 0,
+    dbg_stamps: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
-    """dw (HWIO, pre-zeroed or holding a running sum) += filter gradient."""
+    """dw (HWIO, pre-zeroed or holding a running sum) += filter gradient.
+
+    slot_stride > 0: `dw` is copy 0 of STAT_SLOTS copies spaced slot_stride floats apart in the
+    same storage; each workgroup adds into the copy of its XCD and the caller sums the copies."""
     require()
     b, h, w_, cin = x.shape
     ks, _, cin2, cout = dw.shape
@@ -260,7 +267,11 @@ def conv_wgrad(
     if (b2, ho, wo, cout2, cin2) != (b, eho, ewo, cout, cin):
         raise ValueError("conv_wgrad: shape mismatch")
     d = dict(B=b, H=h, W=w_, Cin=cin, Ho=ho, Wo=wo, Cout=cout, pad=pb, stride=stride, in_mode=IN_RAW,
-             tiles_per_block=tiles_per_block)
+             tiles_per_block=tiles_per_block, dw_slot_stride=slot_stride, co_tiles=co_tiles, debug_skip=debug_skip)
+    if slot_stride:
+        last = (dw.storage_offset() + (STAT_SLOTS - 1) * slot_stride + dw.numel()) * 4
+        if slot_stride < dw.numel() or last > dw.untyped_storage().nbytes():
+            raise ValueError("conv_wgrad: the slot copies do not fit dw's storage")
     d["in"] = _chk(x, "x")
     d["dout"] = _chk(dout, "dout")
     d["dw"] = _chk(dw, "dw")
@@ -269,6 +280,8 @@ def conv_wgrad(
             raise ValueError("in_bn channel mismatch")
         d["in_mode"] = IN_BNRELU
         d["in_bn"] = in_bn.ref()
+    if dbg_stamps is not None:
+        d["dbg_stamps"] = _chk(dbg_stamps, "dbg_stamps", torch.int64)
     hip().conv_wgrad(d, ks, stream())
     return dw
 
@@ -422,6 +435,17 @@ def flat_axpy(y, x, alpha: float):
     if x.numel() != y.numel():
         raise ValueError("flat_axpy: size mismatch")
     hip().flat_axpy(dict(y=_chk(y, "y"), x=_chk(x, "x"), alpha=float(alpha), n=y.numel()), stream())
+    return y
+
+
+def slot_reduce(y: torch.Tensor, slots: torch.Tensor, lo: int, hi: int):
+    """y[lo:hi] += sum_r slots[r, lo:hi]; clears the copies (slots is [STAT_SLOTS, len(y)])."""
+    require()
+    if slots.dim() != 2 or slots.shape[0] != STAT_SLOTS or slots.shape[1] < hi or y.numel() < hi or lo % 4:
+        raise ValueError("slot_reduce: bad shapes")
+    if hi > lo:
+        hip().slot_reduce(dict(y=_chk(y, "y") + 4 * lo, slots=_chk(slots, "slots") + 4 * lo, n=hi - lo,
+                               slot_stride=slots.shape[1]), stream())
     return y
 
 

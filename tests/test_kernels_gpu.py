@@ -159,6 +159,28 @@ def test_conv_wgrad(case):
     close(dw2, want)
 
 
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[5] == 3 and c[3] >= 16])
+@pytest.mark.parametrize("co_tiles,tpb", [(0, 0), (1, 1), (2, 5)])
+def test_conv_wgrad_xcd_slots(case, co_tiles, tpb):
+    b, h, w, cin, cout, ks, s = case
+    if co_tiles and (cout // 16) % co_tiles:
+        pytest.skip("co_tiles does not divide the output tiles")
+    b = 9
+    x = rnd(b, h, w, cin, scale=1.5) + 0.2
+    gamma, beta = rnd(cin).abs() + 0.5, rnd(cin, scale=0.3)
+    a = torch.relu(ref.batch_norm(x, gamma, beta))
+    wt = rnd(ks, ks, cin, cout, scale=0.1).requires_grad_(True)
+    y = ref.conv2d_same(a, wt, s)
+    dy = rnd(*y.shape, seed=19)
+    (want,) = torch.autograd.grad(y, wt, dy)
+    n = want.numel()
+    slots = torch.zeros(nv.STAT_SLOTS, n + 64, device=DEV)
+    dw = slots[0, :n].view(want.shape)
+    nv.conv_wgrad(x, dy, dw, stride=s, in_bn=bn_state_for(x, gamma, beta), slot_stride=n + 64, co_tiles=co_tiles, tiles_per_block=tpb)
+    assert slots[:, n:].abs().max().item() == 0
+    close(slots[:, :n].sum(0).view(want.shape), want)
+
+
 def test_conv_wgrad_bn_prologue():
     b, h, w, cin, cout = 4, 16, 16, 32, 32
     x = rnd(b, h, w, cin, scale=1.5) + 0.2
