@@ -49,6 +49,8 @@ struct ConvFpropArgs {
 // ks in {3,5}; cin_pad in {4,16,32,64}; launches over all B images.
 // Returns the dynamic LDS bytes used (for reporting), throws on unsupported shapes.
 size_t conv_fprop(const ConvFpropArgs& a, int ks, hipStream_t stream);
+// Compile-time band-geometry variant for the 3x3 ResNet shapes; returns 0 when the shape is not covered.
+size_t conv_fprop_band(const ConvFpropArgs& a, int ks, hipStream_t stream);
 // Picks (TH, TW, tiles, cout split) for the given problem; fills the tiling fields of `a`.
 void conv_fprop_plan(ConvFpropArgs& a, int ks);
 

@@ -387,8 +387,16 @@ static bool persist_enabled() {
 }
 
 size_t conv_fprop(const ConvFpropArgs& a_in, int ks, hipStream_t stream) {
-  // 3x3 ResNet shapes run on the persistent, software-pipelined kernel; everything else (and
-  // callers that pin a tiling) on the one-tile-per-block kernel below.
+  // The 3x3 ResNet layer shapes run on the compile-time band-geometry kernel, other 3x3 shapes on
+  // the persistent runtime-geometry kernel; everything else (and callers that pin a tiling) on
+  // the one-tile-per-block kernel below. DTF_CONV_BAND=0 / DTF_CONV_PERSIST=0 disable a tier.
+  static const bool band_on = [] {
+    const char* e = getenv("DTF_CONV_BAND");
+    return !(e && e[0] == '0');
+  }();
+  if (a_in.TH <= 0 && band_on) {
+    if (size_t r = conv_fprop_band(a_in, ks, stream)) return r;
+  }
   if (a_in.TH <= 0 && persist_enabled()) {
     if (size_t r = conv_fprop_persist(a_in, ks, stream)) return r;
   }
