@@ -255,6 +255,8 @@ PYBIND11_MODULE(_hip, m) {
         current_recorder() = nullptr;
       })
       .def("mark_segment", &Program::mark_segment)
+      .def("set_lane", &Program::set_lane)
+      .def("sync_lanes", &Program::sync_lanes)
       .def_property_readonly("num_segments", &Program::num_segments)
       .def_property_readonly("num_records", [](const Program& p) { return p.records.size(); })
       .def("record_names", [](const Program& p) {

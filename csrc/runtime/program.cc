@@ -36,6 +36,8 @@ void issue(const LaunchRecord& r, hipStream_t stream) {
     case LaunchRecord::MEMCPY:
       DTF_HIP_CHECK(hipMemcpyAsync(r.dst, r.src, r.bytes, hipMemcpyDeviceToDevice, stream));
       break;
+    case LaunchRecord::SYNC:
+      throw std::runtime_error("lane synchronisation exists only inside a recorded program");
   }
 }
 
@@ -47,7 +49,7 @@ void memset_async(void* dst, int value, size_t bytes, hipStream_t stream) {
   r.value = value;
   r.bytes = bytes;
   if (Program* p = current_recorder())
-    p->records.push_back(std::move(r));
+    p->push(std::move(r));
   else
     issue(r, stream);
 }
@@ -60,16 +62,45 @@ void memcpy_async(void* dst, const void* src, size_t bytes, hipStream_t stream) 
   r.src = src;
   r.bytes = bytes;
   if (Program* p = current_recorder())
-    p->records.push_back(std::move(r));
+    p->push(std::move(r));
   else
     issue(r, stream);
 }
 
 Program::~Program() {
+  for (hipEvent_t e : events_) (void)hipEventDestroy(e);
+  for (hipStream_t s : side_) (void)hipStreamDestroy(s);
   for (auto& g : graphs_) {
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (g.graph) (void)hipGraphDestroy(g.graph);
   }
+}
+
+void Program::set_lane(int lane) {
+  if (lane < 0 || lane > 7) throw std::runtime_error("Program::set_lane: lane must be 0..7");
+  lane_ = lane;
+}
+
+void Program::sync_lanes(int src_lane, int dst_lane) {
+  if (src_lane == dst_lane) return;
+  LaunchRecord r;
+  r.kind = LaunchRecord::SYNC;
+  r.name = "sync";
+  r.lane = dst_lane;
+  r.src_lane = src_lane;
+  r.event = (int)events_.size();
+  events_.push_back(nullptr);
+  records.push_back(std::move(r));
+}
+
+hipStream_t Program::lane_stream(hipStream_t main, int lane) const {
+  if (lane == 0) return main;
+  while ((int)side_.size() < lane) {
+    hipStream_t s = nullptr;
+    DTF_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    side_.push_back(s);
+  }
+  return side_[lane - 1];
 }
 
 void Program::run(hipStream_t stream, int seg) const {
@@ -79,7 +110,17 @@ void Program::run(hipStream_t stream, int seg) const {
     b = seg_begin[seg];
     e = ((size_t)seg + 1 < seg_begin.size()) ? seg_begin[seg + 1] : records.size();
   }
-  for (size_t i = b; i < e; ++i) issue(records[i], stream);
+  for (size_t i = b; i < e; ++i) {
+    const LaunchRecord& r = records[i];
+    if (r.kind == LaunchRecord::SYNC) {
+      hipEvent_t& ev = events_[r.event];
+      if (!ev) DTF_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      DTF_HIP_CHECK(hipEventRecord(ev, lane_stream(stream, r.src_lane)));
+      DTF_HIP_CHECK(hipStreamWaitEvent(lane_stream(stream, r.lane), ev, 0));
+    } else {
+      issue(r, lane_stream(stream, r.lane));
+    }
+  }
 }
 
 void Program::instantiate(hipStream_t stream, int seg) {

@@ -27,8 +27,14 @@ namespace dtf {
   } while (0)
 
 struct LaunchRecord {
-  enum Kind { KERNEL = 0, MEMSET = 1, MEMCPY = 2 } kind = KERNEL;
+  enum Kind { KERNEL = 0, MEMSET = 1, MEMCPY = 2, SYNC = 3 } kind = KERNEL;
   std::string name;
+  // Lane the record is issued on: lane 0 is the stream handed to run()/replay(), higher lanes
+  // are side streams owned by the program. SYNC makes `lane` wait for everything recorded so
+  // far on `src_lane` (an event recorded on one stream and waited for on the other).
+  int lane = 0;
+  int src_lane = 0;
+  int event = -1;
   const void* fn = nullptr;
   dim3 grid, block;
   size_t shmem = 0;
@@ -48,6 +54,15 @@ class Program {
   std::vector<size_t> seg_begin{0};
 
   void mark_segment() { seg_begin.push_back(records.size()); }
+  // Lane that subsequently recorded launches go to (recording thread only).
+  void set_lane(int lane);
+  int lane() const { return lane_; }
+  // Records: `dst_lane` waits for the work recorded so far on `src_lane`.
+  void sync_lanes(int src_lane, int dst_lane);
+  void push(LaunchRecord&& r) {
+    r.lane = lane_;
+    records.push_back(std::move(r));
+  }
   size_t num_segments() const { return seg_begin.size(); }
   // Issue the launches of one segment (or all with seg < 0) on `stream`.
   void run(hipStream_t stream, int seg = -1) const;
@@ -64,6 +79,10 @@ class Program {
   };
   // slot 0 = whole program, slot i+1 = segment i
   std::vector<GraphSlot> graphs_;
+  int lane_ = 0;
+  mutable std::vector<hipStream_t> side_;   // side_[i] serves lane i+1
+  mutable std::vector<hipEvent_t> events_;
+  hipStream_t lane_stream(hipStream_t main, int lane) const;
 };
 
 // The program currently recording on this thread (nullptr = launch immediately).
@@ -87,7 +106,7 @@ inline void launch(const char* name, void (*kernel)(Args), dim3 grid, dim3 block
   std::memcpy(r.args.data(), &args, sizeof(Args));
   ensure_dynamic_lds(r.fn, shmem);
   if (Program* p = current_recorder()) {
-    p->records.push_back(std::move(r));
+    p->push(std::move(r));
   } else {
     issue(r, stream);
   }

@@ -25,6 +25,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -129,10 +131,14 @@ class ResNetHipStep(StepProgramBase):
         self._pack_table = torch.from_numpy(table.view(np.uint8).copy()).to(dev)
         self._pack_n = len(entries)
 
-        # ---- backward scratch: three rotating gradient buffers of the largest activation
+        # ---- backward scratch: one gradient buffer per tensor, never reused within a step, so the
+        # filter-gradient kernels can trail the data-gradient chain on a side stream without
+        # write-after-read hazards (HBM is plentiful: ~2x the activations)
         if training:
-            big = B * 32 * 32 * 16
-            self._gbuf = [torch.empty(big, **f32) for _ in range(3)]
+            self._d_out = [torch.empty_like(y) for y in self.y]      # gradient of each block output
+            self._d_c1 = [torch.empty_like(c) for c in self.c1]       # gradient through conv2 / BN2
+            self._d_c0 = torch.empty_like(self.c0)
+            self.side_stream = os.environ.get("DTF_SIDE_STREAM", "1") != "0"
             # per-XCD copies of the filter gradients (see ConvWgradArgs::dw_slot_stride), summed into
             # the gradient arena at the end of every bucket segment
             self._wslots = torch.zeros(nv.STAT_SLOTS, arena.total, **f32)
@@ -208,36 +214,53 @@ class ResNetHipStep(StepProgramBase):
                     marks[best[0]] = best[1]
         hi = a.total
 
-        dY, G, G2 = self._gbuf
+        p = self.program
+        side = self.side_stream
+
+        def wgrad(x, dout, name, stride, in_bn=None):
+            # filter gradients are leaves of the dependency graph: they run on lane 1 behind the
+            # kernel that produced `dout`, overlapping the data-gradient chain on lane 0
+            if side:
+                p.sync_lanes(0, 1)
+                p.set_lane(1)
+            self._wgrad(x, dout, name, stride, in_bn)
+            if side:
+                p.set_lane(0)
+
+        def end_bucket(lo, hi_):
+            if side:
+                p.sync_lanes(1, 0)
+            nv.slot_reduce(a.grads, self._wslots, lo, hi_)
+            self.bucket_ranges.append((lo, hi_))
+            p.mark_segment()
+
         x_last = self.y[-1]
-        g = self._view(G, x_last.shape)
-        nv.head_bwd(x_last, self.bnf.fwd, a.param("fc/fc_weights"), self.feat, self.dlogits, g, self.bnf.gsums,
+        dy = self._d_out[-1]
+        nv.head_bwd(x_last, self.bnf.fwd, a.param("fc/fc_weights"), self.feat, self.dlogits, dy, self.bnf.gsums,
                     a.grad("fc/fc_weights"), a.grad("fc/fc_bias"))
-        dy = nv.bn_bwd_apply(g, x_last, self.bnf.fwd, self.bnf.gsums, dgamma=a.grad("fc/gamma"), dbeta=a.grad("fc/beta"),
-                             out=self._view(dY, x_last.shape))
-        bufs = [dY, G, G2]  # bufs[0] always holds the current block-output gradient
+        nv.bn_bwd_apply(dy, x_last, self.bnf.fwd, self.bnf.gsums, dgamma=a.grad("fc/gamma"), dbeta=a.grad("fc/beta"), out=dy)
         for k in range(len(blocks) - 1, -1, -1):
             blk = blocks[k]
             x_in = self.c0 if k == 0 else self.y[k - 1]
             bn1 = self.bn0 if blk.first_block else self.bn1[k]
             bn2 = self.bn2[k]
             c1 = self.c1[k]
-            dy = self._view(bufs[0], self.y[k].shape)
+            dy = self._d_out[k]
             # conv2: filter gradient, masked data gradient, BN backward
-            self._wgrad(c1, dy, blk.conv2.weight, 1, bn2.fwd)
+            wgrad(c1, dy, blk.conv2.weight, 1, bn2.fwd)
             g2 = nv.conv_fprop(dy, self._wpk(blk.conv2.weight, True), ks=3, cout=blk.conv2.cin, pad=1,
                                out_hw=(c1.shape[1], c1.shape[2]), epi_mode=nv.EPI_MASK, mask_src=c1, mask_bn=bn2.fwd,
-                               out_sums=bn2.gsums, out=self._view(bufs[1], c1.shape))
+                               out_sums=bn2.gsums, out=self._d_c1[k])
             dc1 = nv.bn_bwd_apply(g2, c1, bn2.fwd, bn2.gsums, dgamma=a.grad(bn2.gamma_name), dbeta=a.grad(bn2.beta_name), out=g2)
             # conv1
             s = blk.conv1.stride
-            self._wgrad(x_in, dc1, blk.conv1.weight, s, bn1.fwd)
+            wgrad(x_in, dc1, blk.conv1.weight, s, bn1.fwd)
             _, pb, _ = same_pad(x_in.shape[1], 3, s)
             g1 = nv.conv_fprop(dc1, self._wpk(blk.conv1.weight, True), ks=3, cout=blk.conv1.cin, stride=1,
                                upsample=(s == 2), pad=2 - pb, out_hw=(x_in.shape[1], x_in.shape[2]),
                                epi_mode=nv.EPI_MASK, mask_src=x_in, mask_bn=bn1.fwd,
                                extra=dy if blk.first_block else None,
-                               out_sums=bn1.gsums, out=self._view(bufs[2], x_in.shape))
+                               out_sums=bn1.gsums, out=self._d_c0 if k == 0 else self._d_out[k - 1])
             if blk.first_block:
                 res = dict(res_mode=nv.BWD_RES_NONE)
             elif blk.increase_dim:
@@ -246,18 +269,12 @@ class ResNetHipStep(StepProgramBase):
                 res = dict(res_mode=nv.BWD_RES_IDENT, res=dy)
             nv.bn_bwd_apply(g1, x_in, bn1.fwd, bn1.gsums, dgamma=a.grad(bn1.gamma_name), dbeta=a.grad(bn1.beta_name),
                             out=g1, **res)
-            bufs = [bufs[2], bufs[1], bufs[0]]
             if k in marks:
-                nv.slot_reduce(a.grads, self._wslots, marks[k], hi)
-                self.bucket_ranges.append((marks[k], hi))
+                end_bucket(marks[k], hi)
                 hi = marks[k]
-                self.program.mark_segment()
         # stem: filter gradient of conv0 from the raw images
-        dc0 = self._view(bufs[0], self.c0.shape)
-        self._wgrad(self.images, dc0, "conv0/conv", 1)
-        nv.slot_reduce(a.grads, self._wslots, 0, hi)
-        self.bucket_ranges.append((0, hi))
-        self.program.mark_segment()
+        wgrad(self.images, self._d_c0, "conv0/conv", 1)
+        end_bucket(0, hi)
 
     def _record(self, num_buckets: int) -> None:
         p = self.program
