@@ -18,6 +18,8 @@
 // (reference ops: conv2d / conv2d_backprop_input, DistributedResNet/src/resnet.py:99,121,150)
 #include "conv.h"
 
+#include <cstdlib>
+
 namespace dtf {
 namespace {
 
@@ -260,24 +262,29 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_band_kernel(ConvFpropArgs a
       }
 
       if (!(a.debug_skip & 1)) {
+        // Operand fragments are double buffered in registers: the LDS reads of k-group g+1 are in
+        // flight while the MFMAs of k-group g execute; the scheduling barriers pin that order.
+        floatx4 av[2][MTW], bv[2][NT];
+        auto read_group = [&](int g, floatx4 (&ao)[MTW], floatx4 (&bo)[NT]) {
+          const int tap = g / CG, cg = g % CG;
+          const int toff = ((tap / 3) * LW + (tap % 3)) * CPP + cg * 16;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int toff = ((tap / 3) * LW + (tap % 3)) * CPP;
+          for (int i = 0; i < MTW; ++i) ao[i] = *reinterpret_cast<const floatx4*>(s_in + aoff[i] + toff);
 #pragma unroll
-          for (int cg = 0; cg < CG; ++cg) {
-            const int g = tap * CG + cg;
-            floatx4 av[MTW], bv[NT];
+          for (int j = 0; j < NT; ++j) bo[j] = *reinterpret_cast<const floatx4*>(s_w + (g * NT + j) * 256 + lane * 4);
+        };
+        read_group(0, av[0], bv[0]);
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) av[i] = *reinterpret_cast<const floatx4*>(s_in + aoff[i] + toff + cg * 16);
+        for (int g = 0; g < KG; ++g) {
+          if (g + 1 < KG) read_group(g + 1, av[(g + 1) & 1], bv[(g + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const floatx4*>(s_w + (g * NT + j) * 256 + lane * 4);
+          for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int i = 0; i < MTW; ++i)
 #pragma unroll
-              for (int i = 0; i < MTW; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = DTF_MFMA16(bv[j][s], av[i][s], acc[i][j]);
-          }
+              for (int j = 0; j < NT; ++j) acc[i][j] = DTF_MFMA16(bv[g & 1][j][s], av[g & 1][i][s], acc[i][j]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
 
@@ -365,9 +372,15 @@ size_t launch_fband(const ConvFpropArgs& a, hipStream_t stream) {
   const size_t shmem = (size_t)G::LDS_FLOATS * sizeof(float);
   const int zsplit = a.nt_total / NT;
   const int total_tiles = (a.Ho / TH) * a.B;
-  int bpc = (int)((160 * 1024) / shmem);
-  if (bpc > 2) bpc = 2;   // register budget of __launch_bounds__(256, 2)
-  if (bpc < 1) bpc = 1;
+  // co-resident blocks per CU as the runtime sees them (LDS and the registers the instance really uses)
+  static const int bpc = [&] {
+    const char* e = getenv("DTF_CONV_BPC");
+    if (e && atoi(e) > 0) return atoi(e);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(conv_fprop_band_kernel<S, CP, NT, TW, TH, UPS, BWD>), shmem);
+    int n = 0;
+    DTF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_fprop_band_kernel<S, CP, NT, TW, TH, UPS, BWD>, 256, shmem));
+    return n < 1 ? 1 : n;
+  }();
   int gpz_max = (256 * bpc) / zsplit;
   if (gpz_max < 8) gpz_max = 8;
   // even work: iterations = ceil(tiles / gpz_max), then the smallest multiple-of-8 grid that needs no more

@@ -192,24 +192,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(ConvWgradArgs a
     if (t + 1 < t_end) load_band(t + 1);   // in flight during the MFMA loop
 
     if (!(a.debug_skip & 1)) {
-      float af[9][NA], bf[NB];
-      read_frags(wx, af, bf);
-      for (int step = wx; step < G::STEPS; step += WX) {
-        float af_n[9][NA], bf_n[NB];
-        const int nxt = step + WX < G::STEPS ? step + WX : step;
-        read_frags(nxt, af_n, bf_n);
+      // Two fragment sets alternate: while the nine-tap MFMA group of one k-step executes, the LDS
+      // reads of the next k-step are already in flight. The scheduling barriers keep the compiler
+      // from sinking the reads below the MFMAs (it otherwise waits for LDS once per k-step).
+      static_assert((G::STEPS / WX) % 2 == 0, "k-steps per wave must be even");
+      float af0[9][NA], bf0[NB], af1[9][NA], bf1[NB];
+      auto mfma_group = [&](float (&af)[9][NA], float (&bf)[NB]) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
           for (int i = 0; i < NA; ++i)
 #pragma unroll
             for (int j = 0; j < NB; ++j) acc[tap][i * NB + j] = DTF_MFMA16(af[tap][i], bf[j], acc[tap][i * NB + j]);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-          for (int i = 0; i < NA; ++i) af[tap][i] = af_n[tap][i];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) bf[j] = bf_n[j];
+      };
+      read_frags(wx, af0, bf0);
+      for (int step = wx; step < G::STEPS; step += 2 * WX) {
+        read_frags(step + WX, af1, bf1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(step + 2 * WX < G::STEPS ? step + 2 * WX : step, af0, bf0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(af1, bf1);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();   // all waves are done with this band's LDS tile

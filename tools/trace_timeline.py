@@ -9,9 +9,9 @@ import sys
 def short(n: str) -> str:
     m = re.search(r"(\w+_kernel)", n)
     base = m.group(1) if m else n[:40]
-    t = re.search(r"IL[ib]\d+E(?:L[ib]\d+E)*", n)
+    t = re.search(r"_kernel<([^>]*)>", n)
     if t:
-        base += "<" + ",".join(re.findall(r"L[ib](\d+)E", t.group(0))) + ">"
+        base += "<" + t.group(1).replace(" ", "").replace("false", "0").replace("true", "1") + ">"
     return base
 
 
