@@ -119,6 +119,12 @@ class Communicator:
         lo, hi = bounds[self.rank]
         if self.world == 1:
             return flat[lo:hi]
+        if flat.is_cuda and self.info.backend == "gloo":
+            torch.cuda.current_stream().synchronize()
+            host = flat.detach().cpu()
+            self.reduce_scatter_flat(host, bounds)
+            flat[lo:hi].copy_(host[lo:hi])
+            return flat[lo:hi]
         sizes = {b[1] - b[0] for b in bounds}
         if len(sizes) == 1 and self.info.backend == "nccl":
             dist.reduce_scatter_tensor(flat[lo:hi], flat[: bounds[-1][1]], op=dist.ReduceOp.SUM)
@@ -131,6 +137,12 @@ class Communicator:
     def all_gather_flat(self, flat: torch.Tensor, bounds: Sequence[Tuple[int, int]]) -> None:
         """Every rank broadcasts its shard flat[bounds[rank]] into the same range on all ranks."""
         if self.world == 1:
+            return
+        if flat.is_cuda and self.info.backend == "gloo":
+            torch.cuda.current_stream().synchronize()
+            host = flat.detach().cpu()
+            self.all_gather_flat(host, bounds)
+            flat.copy_(host)
             return
         works = [dist.broadcast(flat[b[0]:b[1]], src=r, async_op=True) for r, b in enumerate(bounds)]
         for w in works:

@@ -77,11 +77,31 @@ class FullSync(Strategy):
 
     def step(self, replica, step: int, lr: float) -> StepResult:
         t0 = time.time()
+        if self.reduce_scatter and self.world > 1:
+            return self._step_sharded(replica, lr, t0)
         replica.forward_backward(on_bucket=lambda lo, hi: self.comm.all_reduce_async(replica.arena.grads[lo:hi]))
         dt = time.time() - t0
         with replica.stream_ctx():
             self.comm.wait_all()
         replica.apply_update(lr, grad_scale=1.0 / self.world)
+        return StepResult(True, self.world, False, True, dt)
+
+    def _step_sharded(self, replica, lr: float, t0: float) -> StepResult:
+        """Reduce-scatter + sharded optimizer + all-gather: every rank owns a contiguous 1/N of
+        the parameters and of the optimizer slots, reduces only that range of the gradient,
+        updates it, and the updated ranges are gathered back. Moves the same bytes as the
+        all-reduce but the optimizer reads 1/N of the state per rank; it is also the layout of
+        the asynchronous parameter shards (parallel/async_ps.py)."""
+        a = replica.arena
+        bounds = a.shard_bounds(self.world)
+        replica.forward_backward()
+        dt = time.time() - t0
+        lo, hi = bounds[self.rank]
+        with replica.stream_ctx():
+            self.comm.reduce_scatter_flat(a.grads, bounds)
+        replica.apply_update_shard(lr, 1.0 / self.world, lo, hi)
+        with replica.stream_ctx():
+            self.comm.all_gather_flat(a.params, bounds)
         return StepResult(True, self.world, False, True, dt)
 
 

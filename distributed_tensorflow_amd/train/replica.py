@@ -134,6 +134,17 @@ class TorchReplica(ReplicaBase):
             ref.momentum_update(a.params, g, a.slots["m"], lr, self.momentum, self.weight_decay)
         self.updates_applied += 1
 
+    def apply_update_shard(self, lr: float, grad_scale: float, lo: int, hi: int) -> None:
+        """Optimizer over the flat range [lo, hi) only (sharded-optimizer mode: this replica owns
+        that range of parameters and optimizer slots)."""
+        a = self.arena
+        g = a.grads[lo:hi] * grad_scale if grad_scale != 1.0 else a.grads[lo:hi]
+        if self.optimizer == "adam":
+            ref.adam_update(a.params[lo:hi], g, a.slots["m"][lo:hi], a.slots["v"][lo:hi], self.adam_lr_t(lr))
+        else:
+            ref.momentum_update(a.params[lo:hi], g, a.slots["m"][lo:hi], lr, self.momentum, self.weight_decay)
+        self.updates_applied += 1
+
     def zero_grads(self) -> None:
         self.arena.grads.zero_()
 
@@ -180,8 +191,11 @@ class HipReplica(ReplicaBase):
                 self.step = LeNetHipStep(batch_size, self.arena, optimizer=optimizer, num_buckets=num_buckets)
             else:
                 self.step = ResNetHipStep(num_residual_blocks, batch_size, self.arena, optimizer=optimizer, num_buckets=num_buckets)
-            self.use_graph = use_graph
-            if use_graph:
+            # A step that trails its filter gradients on a side stream is issued from C++ on two
+            # real streams: hipGraph replay of the forked graph was measured slower (cross-queue
+            # dependencies cost ~10 us each).
+            self.use_graph = use_graph and not getattr(self.step, "side_stream", False)
+            if self.use_graph:
                 self.step.instantiate(per_segment=True)
         self.stream.synchronize()
         self.bucket_ranges = list(self.step.bucket_ranges)
@@ -231,6 +245,21 @@ class HipReplica(ReplicaBase):
             lr_t = self.adam_lr_t(lr) if self.optimizer == "adam" else lr
             st.set_hyper(lr_t=lr_t, grad_scale=grad_scale, momentum=self.momentum, weight_decay=self.weight_decay)
             st.run(st.num_segments - 1, self.use_graph)
+        self.updates_applied += 1
+
+    def apply_update_shard(self, lr: float, grad_scale: float, lo: int, hi: int) -> None:
+        """Fused optimizer launch over the flat range [lo, hi) only (sharded-optimizer mode)."""
+        from ..ops import native as nv
+
+        st, a = self.step, self.arena
+        with torch.cuda.stream(self.stream):
+            lr_t = self.adam_lr_t(lr) if self.optimizer == "adam" else lr
+            st.set_hyper(lr_t=lr_t, grad_scale=grad_scale, momentum=self.momentum, weight_decay=self.weight_decay)
+            if hi > lo:
+                if self.optimizer == "adam":
+                    nv.fused_adam(a.params[lo:hi], a.grads[lo:hi], a.slots["m"][lo:hi], a.slots["v"][lo:hi], st.hyper)
+                else:
+                    nv.fused_momentum_sgd(a.params[lo:hi], a.grads[lo:hi], a.slots["m"][lo:hi], st.hyper)
         self.updates_applied += 1
 
     def zero_grads(self) -> None:

@@ -95,7 +95,10 @@ def _gpu_sync_worker(rank, world, board_name, mode):
     g = torch.Generator().manual_seed(50 + rank)
     rep.load_batch(torch.randn(16, 32, 32, 3, generator=g), torch.randint(0, 10, (16,), generator=g))
     control_plane.launch_manager(board, rank, world, 120)
-    strat = FullSync(comm, board) if mode == "sync" else Backup(comm, board, world - 1)
+    if mode == "backup":
+        strat = Backup(comm, board, world - 1)
+    else:
+        strat = FullSync(comm, board, reduce_scatter=(mode == "sharded"))
     losses = []
     for it in range(6):
         res = strat.step(rep, it, 1e-3)
@@ -107,7 +110,7 @@ def _gpu_sync_worker(rank, world, board_name, mode):
     return dict(losses=losses, psum=psum, updates=rep.updates_applied)
 
 
-@pytest.mark.parametrize("mode", ["sync", "backup"])
+@pytest.mark.parametrize("mode", ["sync", "backup", "sharded"])
 def test_two_gpu_replicas_stay_identical(mode):
     out = run_workers(_gpu_sync_worker, 2, f"dtf_g_{mode}_{os.getpid()}", mode, timeout=300)
     assert abs(out[0]["psum"] - out[1]["psum"]) < 1e-6 * max(1.0, abs(out[0]["psum"]))

@@ -33,7 +33,7 @@ def _grads_of(rep):
     return rep.arena.grads.clone()
 
 
-def _full_sync_worker(rank, world, board_name):
+def _full_sync_worker(rank, world, board_name, sharded=False):
     from distributed_tensorflow_amd.parallel.strategies import FullSync
 
     comm, board, rep, images, labels = _setup(rank, world, board_name)
@@ -42,7 +42,7 @@ def _full_sync_worker(rank, world, board_name):
     torch.distributed.all_gather(gathered, own)
     mean = torch.stack(gathered).mean(0)
     p0 = rep.arena.params.clone()
-    res = FullSync(comm, board).step(rep, 0, 1e-3)
+    res = FullSync(comm, board, reduce_scatter=sharded).step(rep, 0, 1e-3)
     # expected: Adam's first step on the mean gradient
     from distributed_tensorflow_amd.ops import reference as ref
 
@@ -59,6 +59,13 @@ def test_full_sync_is_the_mean_of_all_replicas():
     assert all(c == 3 for c, _, _ in out)
     assert all(e < 1e-6 for _, e, _ in out)
     assert len({round(s, 4) for _, _, s in out}) == 1           # identical parameters everywhere
+
+
+def test_sharded_optimizer_matches_the_replicated_update():
+    # reduce-scatter + per-shard Adam + all-gather must give the same parameters as all-reduce + full Adam
+    out = run_workers(_full_sync_worker, 3, f"dtf_t_rs_{os.getpid()}", True)
+    assert all(e < 1e-6 for _, e, _ in out)
+    assert len({round(s, 4) for _, _, s in out}) == 1
 
 
 def _backup_worker(rank, world, board_name, m, slow_rank):
