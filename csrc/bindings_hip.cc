@@ -8,6 +8,7 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include "comm/p2p_allreduce.h"
 #include "kernels/conv.h"
 #include "kernels/ops.h"
 #include "runtime/program.h"
@@ -171,6 +172,29 @@ PYBIND11_MODULE(_hip, m) {
     P(y, float); P(slots, float); V(n); V(slot_stride);
     slot_reduce(a, as_stream(stream));
   });
+  // ---------------------------------------------------------------- peer-to-peer collective
+  m.def("p2p_allreduce", [](const py::dict& d, int blocks, uint64_t stream) {
+    P2PAllReduceArgs a{};
+    auto xb = d["xbuf"].cast<std::vector<uint64_t>>();
+    auto fl = d["flags"].cast<std::vector<uint64_t>>();
+    auto w = d["weight"].cast<std::vector<float>>();
+    V(rank); V(world); V(n); V(seq); V(timeout_ticks);
+    if ((int)xb.size() != a.world || (int)fl.size() != a.world || (int)w.size() != a.world || a.world > kMaxPeers)
+      throw std::runtime_error("p2p_allreduce: per-rank lists must have `world` entries");
+    for (int p = 0; p < a.world; ++p) {
+      a.xbuf[p] = reinterpret_cast<float*>(xb[p]);
+      a.flags[p] = reinterpret_cast<uint32_t*>(fl[p]);
+      a.weight[p] = w[p];
+    }
+    P(data, float); P(error, int);
+    p2p_allreduce(a, blocks, as_stream(stream));
+  });
+  m.attr("P2P_FLAG_BLOCK_BYTES") = (uint64_t)kFlagBlockBytes;
+  m.def("ipc_alloc", [](uint64_t bytes, bool fine) { return (uint64_t)ipc_alloc(bytes, fine); });
+  m.def("ipc_free", [](uint64_t p) { ipc_free(reinterpret_cast<void*>(p)); });
+  m.def("ipc_export", [](uint64_t p) { return py::bytes(ipc_export(reinterpret_cast<void*>(p))); });
+  m.def("ipc_import", [](const py::bytes& h) { return (uint64_t)ipc_import(std::string(h)); });
+  m.def("ipc_release", [](uint64_t p) { ipc_release(reinterpret_cast<void*>(p)); });
   m.def("memset", [](uint64_t dst, int value, uint64_t bytes, uint64_t stream) {
     memset_async(reinterpret_cast<void*>(dst), value, bytes, as_stream(stream));
   });

@@ -37,6 +37,7 @@ class Communicator:
         self.info = info
         self._owns = owns_group
         self._pending: List = []
+        self.p2p = None   # optional hand-written peer-to-peer all-reduce (parallel/p2p.py)
 
     # -- construction ----------------------------------------------------------------------------
     @classmethod
@@ -92,6 +93,9 @@ class Communicator:
         runs on the process group's own stream, ordered after everything already enqueued on the
         current stream, so later kernels on the current stream overlap with it."""
         if self.world == 1:
+            return
+        if self.p2p is not None and flat.is_cuda:
+            self.p2p.all_reduce(flat)   # stream-ordered kernel on the current stream
             return
         if flat.is_cuda and self.info.backend == "gloo":
             # gloo is the CPU control/test plane: stage device buffers through the host
@@ -173,7 +177,17 @@ class Communicator:
         dist.all_gather_object(out, obj)
         return out
 
+    def enable_p2p(self, max_floats: int, **kw) -> None:
+        """Routes all_reduce_async of GPU buffers through the peer-to-peer kernel."""
+        from .p2p import P2PAllReduce
+
+        if self.world > 1 and self.info.device.type == "cuda":
+            self.p2p = P2PAllReduce(self, max_floats, **kw)
+
     def close(self) -> None:
+        if self.p2p is not None:
+            self.p2p.close()
+            self.p2p = None
         if self._owns and dist.is_initialized():
             dist.destroy_process_group()
             self._owns = False

@@ -161,6 +161,11 @@ def train(flags, model: str) -> Dict:
             comm.broadcast(t, 0)
     replica.synchronize()
 
+    if flags.allreduce_impl == "p2p":
+        comm.enable_p2p(replica.arena.grads_full.numel())
+    elif flags.allreduce_impl != "rccl":
+        raise ValueError("--allreduce_impl must be rccl or p2p")
+
     async_mode = flags.async_method
     if async_mode:
         from ..parallel.async_ps import AsyncParameterShards

@@ -95,6 +95,8 @@ def _gpu_sync_worker(rank, world, board_name, mode):
     g = torch.Generator().manual_seed(50 + rank)
     rep.load_batch(torch.randn(16, 32, 32, 3, generator=g), torch.randint(0, 10, (16,), generator=g))
     control_plane.launch_manager(board, rank, world, 120)
+    if mode == "p2p":
+        comm.enable_p2p(rep.arena.grads_full.numel(), blocks=8)
     if mode == "backup":
         strat = Backup(comm, board, world - 1)
     else:
@@ -110,7 +112,7 @@ def _gpu_sync_worker(rank, world, board_name, mode):
     return dict(losses=losses, psum=psum, updates=rep.updates_applied)
 
 
-@pytest.mark.parametrize("mode", ["sync", "backup", "sharded"])
+@pytest.mark.parametrize("mode", ["sync", "backup", "sharded", "p2p"])
 def test_two_gpu_replicas_stay_identical(mode):
     out = run_workers(_gpu_sync_worker, 2, f"dtf_g_{mode}_{os.getpid()}", mode, timeout=300)
     assert abs(out[0]["psum"] - out[1]["psum"]) < 1e-6 * max(1.0, abs(out[0]["psum"]))

@@ -1,0 +1,43 @@
+"""Hand-written peer-to-peer all-reduce: several processes share the one available GPU and map
+each other's exchange buffers through HIP IPC (on a multi-GPU node the same mappings go over xGMI)."""
+import os
+
+import pytest
+import torch
+
+from mp_util import run_workers
+
+pytestmark = pytest.mark.gpu
+
+
+def _p2p_worker(rank, world, board_name, n):
+    import torch
+
+    from distributed_tensorflow_amd.parallel.comm import Communicator
+    from distributed_tensorflow_amd.parallel.p2p import P2PAllReduce
+
+    os.environ["LOCAL_RANK"] = "0"
+    comm = Communicator.from_env(backend="gloo")
+    p2p = P2PAllReduce(comm, n, blocks=8, timeout_s=20.0)
+    errs = []
+    cases = [None, [1.0] * (world - 1) + [0.0], [0.5 * (r + 1) for r in range(world)], None]
+    for it, w in enumerate(cases):
+        contrib = [torch.randn(n, generator=torch.Generator().manual_seed(1000 * it + r)) for r in range(world)]
+        ww = [1.0] * world if w is None else w
+        want = sum(c.double() * wr for c, wr in zip(contrib, ww))
+        m = n if it != 3 else n - 64     # a shorter bucket reuses the front of the exchange buffer
+        x = contrib[rank][:m].cuda()
+        p2p.all_reduce(x, w)
+        torch.cuda.synchronize()
+        p2p.check()
+        errs.append(float((x.double().cpu() - want[:m]).abs().max()))
+    p2p.close()
+    comm.close()
+    return errs
+
+
+@pytest.mark.parametrize("world,n", [(2, 4096), (3, 100_000)])
+def test_p2p_allreduce_matches_weighted_sum(world, n):
+    out = run_workers(_p2p_worker, world, f"dtf_p2p_{os.getpid()}", n, timeout=240)
+    for errs in out:
+        assert max(errs) < 1e-4, errs
