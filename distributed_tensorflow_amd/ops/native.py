@@ -574,12 +574,15 @@ def zero_fraction(x) -> float:
     return float(z.item()) / max(1, x.numel())
 
 
-def crop_whiten(src, index=None, offs=None, out_hw=None, whiten=True):
+def crop_whiten(src, index=None, offs=None, out_hw=None, whiten=True, out=None):
     require()
     n, hp, wp, c = src.shape
     h, w_ = out_hw if out_hw is not None else (hp, wp)
     b = index.numel() if index is not None else n
-    out = torch.empty((b, h, w_, c), device=src.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((b, h, w_, c), device=src.device, dtype=torch.float32)
+    elif tuple(out.shape) != (b, h, w_, c):
+        raise ValueError("crop_whiten: out has the wrong shape")
     d = dict(src=_chk(src, "src"), out=_chk(out, "out"), B=b, HP=hp, WP=wp, H=h, W=w_, C=c, whiten=int(whiten))
     if index is not None:
         d["index"] = _chk(index, "index", torch.int32)

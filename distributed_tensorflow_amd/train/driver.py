@@ -73,6 +73,18 @@ class _CifarFeed:
     def next(self):
         return self.batcher.next_batch(self.batch_size)
 
+    def to_gpu(self, device) -> None:
+        """Moves the padded dataset into HBM; from then on `feed_into` crops + whitens on the GPU."""
+        b = self.batcher
+        gb = cifar_data.GpuTrainBatcher(b.data, b.labels, b.padding, None, device)
+        gb.rng = b.rng   # continue the same random stream
+        self.gpu_batcher = gb
+
+    def feed_into(self, replica) -> None:
+        st = replica.step
+        with replica.stream_ctx():
+            self.gpu_batcher.next_batch_into(st.images, st.labels)
+
 
 def _inject_straggler(flags, rank: int, rng: random.Random) -> None:
     if flags.inject_straggler_ms <= 0 or not flags.inject_straggler_ranks:
@@ -147,6 +159,10 @@ def train(flags, model: str) -> Dict:
         momentum=flags.momentum, weight_decay=flags.weight_decay if flags.optimizer == "momentum" else 0.0,
         num_buckets=buckets, use_graph=flags.hip_graph,
     )
+    # ResNet on the GPU: the dataset lives in HBM and augmentation is one kernel per step
+    gpu_feed = model == "resnet" and hasattr(replica, "step") and flags.gpu_data_pipeline
+    if gpu_feed:
+        feed.to_gpu(replica.device)
     saver = Saver(replica.arena, flags.optimizer, flags.checkpoint_names)
     sv = Supervisor(saver, train_dir, is_chief, flags.save_interval_secs)
     global_step = 0
@@ -211,8 +227,11 @@ def train(flags, model: str) -> Dict:
                     break
             timeout_client.broadcast_worker_dequeued_token(cur_iteration)
         start_time = time.time()
-        images, labels = feed.next()
-        replica.load_batch(images, labels)
+        if gpu_feed:
+            feed.feed_into(replica)
+        else:
+            images, labels = feed.next()
+            replica.load_batch(images, labels)
         _inject_straggler(flags, rank, rng)
         timeline.reset()
         log.info("RUNNING SESSION... %f" % time.time())
@@ -229,6 +248,12 @@ def train(flags, model: str) -> Dict:
                 global_step += 1
             aborted_steps += int(res.aborted)
             excluded_steps += int(not res.included)
+            # per-step aggregator record: what the reference observes with tf.Print on the
+            # parameter server (accumulated count, local vs global step, who was dropped;
+            # reference: DistributedLeNet/src/soft_kill_optimizer.py:425-442,465-469)
+            log.debug("AGGREGATOR worker=%d iter=%d policy=%s applied=%s contributors=%d included=%s aborted=%s "
+                      "local_step=%d global_step=%d compute_s=%.6f", rank, cur_iteration, strategy.name, res.applied,
+                      res.contributors, res.included, res.aborted, cur_iteration, global_step, res.compute_s)
             step = global_step
             if board is not None and is_chief:
                 board.set_global_step(global_step)
@@ -262,6 +287,9 @@ def train(flags, model: str) -> Dict:
             log.info("Running Summary operation on the chief.")
             scalars = {"loss": loss_value, "learning_rate": lr_mod.exponential_decay(
                 flags.initial_learning_rate, global_step, decay_steps, flags.learning_rate_decay_factor)}
+            # activation sparsity of every conv output (reference: activation_summary,
+            # DistributedResNet/src/resnet.py:13-20)
+            scalars.update(getattr(getattr(replica, "step", None), "activation_sparsity", dict)())
             summary_writer.add_scalars(scalars, step)
             log.info("Finished running Summary operation.")
             next_summary_time += flags.save_summaries_secs

@@ -91,3 +91,19 @@ def test_every_reference_cfg_file_parses_and_expands():
         assert rest == [], (f, rest)
         ev = cfg_mod.evaluate_flags(c)
         assert ev["checkpoint_dir"].endswith("train_dir")
+
+
+def test_own_cfg_files_parse_and_expand():
+    """The cfg files generated for the 8-GPU node (tools/make_cfgs.py) load through the same Cfg
+    machinery as the reference's files and expand to flags the entry scripts accept."""
+    import glob
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [f for f in glob.glob(os.path.join(root, "Distributed*", "cfg", "**", "*"), recursive=True) if os.path.isfile(f)]
+    assert len(files) >= 20
+    for f in files:
+        c = cfg_mod.load_cfg_from_file(f)
+        flags = cfg_mod.train_flags(c)
+        assert flags["train_dir"].endswith("/train_dir"), f
+        assert int(flags["batch_size"]) > 0
+        assert c["base_out_dir"] == "runs/" + c["name"]

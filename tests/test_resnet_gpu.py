@@ -121,3 +121,22 @@ def test_eval_program_counts_top1():
     logits = resnet_forward(arena.state_dict(), images, n)
     assert ev.correct_count() == ref.top1_hits(logits, labels)
     assert abs(ev.loss_value() - ref.softmax_xent_mean(logits, labels).item()) < 1e-3
+
+
+def test_gpu_batcher_matches_host_batcher():
+    import numpy as np
+
+    from distributed_tensorflow_amd.data import cifar10 as cd
+
+    data, labels = cd.synthetic_cifar(96, 5)
+    padded = cd.pad_images(data, 2)
+    host = cd.TrainBatcher(padded.copy(), labels.copy(), 2, seed=11)
+    gpu = cd.GpuTrainBatcher(padded, labels, 2, seed=11)
+    images = torch.empty(40, 32, 32, 3, device="cuda")
+    lab = torch.empty(40, device="cuda", dtype=torch.int32)
+    for _ in range(4):   # crosses an epoch boundary (reshuffle)
+        want_x, want_y = host.next_batch(40)
+        gpu.next_batch_into(images, lab)
+        torch.cuda.synchronize()
+        assert np.array_equal(lab.cpu().numpy(), want_y)
+        assert np.abs(images.cpu().numpy() - want_x).max() < 2e-4
