@@ -51,6 +51,8 @@ struct ConvFpropArgs {
 size_t conv_fprop(const ConvFpropArgs& a, int ks, hipStream_t stream);
 // Compile-time band-geometry variant for the 3x3 ResNet shapes; returns 0 when the shape is not covered.
 size_t conv_fprop_band(const ConvFpropArgs& a, int ks, hipStream_t stream);
+// Parity-decomposed data gradient of a 3x3 stride-2 layer (the `upsample` call); 0 = not covered.
+size_t conv_dgrad_s2(const ConvFpropArgs& a, int ks, hipStream_t stream);
 // Picks (TH, TW, tiles, cout split) for the given problem; fills the tiling fields of `a`.
 void conv_fprop_plan(ConvFpropArgs& a, int ks);
 

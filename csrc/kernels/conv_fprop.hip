@@ -395,6 +395,9 @@ size_t conv_fprop(const ConvFpropArgs& a_in, int ks, hipStream_t stream) {
     return !(e && e[0] == '0');
   }();
   if (a_in.TH <= 0 && band_on) {
+    if (a_in.upsample) {
+      if (size_t r = conv_dgrad_s2(a_in, ks, stream)) return r;
+    }
     if (size_t r = conv_fprop_band(a_in, ks, stream)) return r;
   }
   if (a_in.TH <= 0 && persist_enabled()) {

@@ -198,7 +198,10 @@ void head_bwd(const HeadBwdArgs& a, hipStream_t stream) {
   if (a.K > kMaxK || a.C > kMaxC || (a.C & 3) || (256 % (a.C / 4)) != 0)
     throw std::runtime_error("head_bwd: unsupported C/K");
   launch("head_bwd", head_bwd_kernel, dim3(a.B), dim3(256), 0, stream, a);
-  const int splits = a.B >= 64 ? 8 : 1;
+  // ~16 samples per thread: the loop is a chain of dependent loads, so depth, not atomics, sets its time
+  int splits = a.B / 16;
+  if (splits < 1) splits = 1;
+  if (splits > 128) splits = 128;
   launch("head_param_grad", head_param_grad_kernel, dim3(ceil_div(a.C * a.K + a.K, 256), splits), dim3(256), 0, stream, a);
 }
 

@@ -118,6 +118,34 @@ def test_conv_dgrad(case):
     close(got, want)
 
 
+@pytest.mark.parametrize("shape", [(5, 32, 16, 32), (3, 16, 32, 64)])
+@pytest.mark.parametrize("with_extra", [False, True])
+def test_conv_dgrad_stride2_mask_epilogue(shape, with_extra):
+    # data gradient of a stride-2 layer with the ReLU mask and BatchNorm-backward sums (parity-decomposed kernel)
+    b, h, cin, cout = shape
+    x_pre = rnd(b, h, h, cin, scale=1.5)
+    gamma, beta = rnd(cin).abs() + 0.5, rnd(cin, scale=0.3)
+    wt = rnd(3, 3, cin, cout, scale=0.1)
+    a = torch.relu(ref.batch_norm(x_pre, gamma, beta)).requires_grad_(True)
+    y = ref.conv2d_same(a, wt, 2)
+    dy = rnd(*y.shape, seed=23)
+    extra = rnd(b, h, h, cin, seed=29) if with_extra else None
+    (da,) = torch.autograd.grad(y, a, dy)
+    bn_x = ref.batch_norm(x_pre, gamma, beta)
+    want = torch.where(bn_x > 0, da + (extra if with_extra else 0), torch.zeros_like(da))
+    st = bn_state_for(x_pre, gamma, beta)
+    gs = nv.new_stats(cin, DEV)
+    _, pb, _ = ref.same_pad(h, 3, 2)
+    got = nv.conv_fprop(dy, nv.pack_weights(wt, flip=True), ks=3, cout=cin, stride=1, upsample=True, pad=2 - pb, out_hw=(h, h),
+                        epi_mode=nv.EPI_MASK, mask_src=x_pre, mask_bn=st, extra=extra, out_sums=gs)
+    close(got, want)
+    mean, var = ref.batch_moments(x_pre)
+    xhat = (x_pre - mean) * torch.rsqrt(var + ref.BN_EPSILON)
+    gt = nv.stats_total(gs)
+    close(gt[:cin], want.reshape(-1, cin).double().sum(0), 1e-4)
+    close(gt[cin:], (want * xhat).reshape(-1, cin).double().sum(0), 1e-4)
+
+
 def test_conv_dgrad_mask_epilogue():
     b, h, w, cin, cout = 4, 16, 16, 32, 32
     x_pre = rnd(b, h, w, cin, scale=1.5)          # BN input of the layer below
