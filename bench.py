@@ -59,6 +59,10 @@ def main() -> None:
                          "cross-queue dependencies between the branches, measured slower (1.47 vs 1.24 ms/step)")
     ap.add_argument("--no-graph", action="store_true", help="same as --graph off")
     ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--backend", default=None, help="torch.distributed backend; default nccl (= RCCL). gloo lets several "
+                                                     "ranks share one GPU to rehearse the multi-rank path")
+    ap.add_argument("--allreduce", choices=["rccl", "p2p"], default="rccl",
+                    help="gradient all-reduce: RCCL, or the hand-written two-shot kernel over peer-mapped HBM")
     args = ap.parse_args()
 
     from distributed_tensorflow_amd.models.resnet_hip import ResNetHipStep
@@ -67,7 +71,7 @@ def main() -> None:
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; for the CPU floor run bench/cpu_reference.py")
-    comm = Communicator.from_env()
+    comm = Communicator.from_env(backend=args.backend)
     world = comm.world
     if world != args.gpus and comm.is_chief:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
@@ -79,6 +83,8 @@ def main() -> None:
         step = ResNetHipStep(n, args.batch, optimizer=args.optimizer, num_buckets=args.buckets if world > 1 else 1)
         # identical initial parameters on every replica
         comm.broadcast(step.arena.params, 0)
+        if args.allreduce == "p2p":
+            comm.enable_p2p(step.arena.grads_full.numel())
         images = torch.randn(args.batch, 32, 32, 3, device=comm.device)
         labels = torch.randint(0, 10, (args.batch,), device=comm.device)
         step.load_batch(images, labels)
@@ -146,7 +152,7 @@ def main() -> None:
             "config": {
                 "model": args.model, "global_batch": args.batch * world, "per_gpu_batch": args.batch,
                 "reference_worker_batch": 256, "seq_len": None, "image": "32x32x3", "optimizer": args.optimizer,
-                "parallelism": f"dp{world}", "hip_graph": graph, "grad_buckets": len(ranges),
+                "parallelism": f"dp{world}", "hip_graph": graph, "allreduce": args.allreduce if world > 1 else "none", "grad_buckets": len(ranges),
                 "kernels_per_step": step.kernel_count, "final_loss": round(loss, 4),
                 "baseline": "CPU reference floor (bench/cpu_floor.json); the reference publishes no numbers",
             },

@@ -37,6 +37,8 @@ struct FBand {
   static constexpr int NW = (W_CHUNKS + 255) / 256;
   static constexpr int N_MT = TH * TW / 16;
   static constexpr int MTW = (N_MT >= 8 && NT <= 2) ? 2 : 1;
+  static constexpr int ITER = N_MT / (4 * MTW);          // m-tile groups per wave and tile
+  static_assert(N_MT % (4 * MTW) == 0, "every wave gets the same number of m-tile groups");
   static constexpr int IN_FLOATS = (LH * LW * CPP + 3) & ~3;
   static constexpr int W_FLOATS = KG * NT * 256;
   static constexpr int LDS_FLOATS = IN_FLOATS + W_FLOATS + 2 * CP + 7 * NT * 16;
@@ -127,12 +129,42 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_band_kernel(ConvFpropArgs a
     in_loff[k] = pix * CPP + c4 * 4;
     in_row[k] = ok ? rr : -100000;
   }
+  // lane-constant parts of the LDS pixel address and of the output offset (pixel l15 of an m-tile)
+  const int lane_a = (((l15 / TW) * S) * LW + (l15 % TW) * S) * CPP + 4 * q;
+  const int lane_o = l15 * a.Cout + z * NT * 16 + 4 * q;
+  const bool want_res = !BWD && ((a.res_mode == RES_IDENT) || (a.res_mode == RES_BNRELU));
+
+  // Epilogue operands (residual / mask source / extra gradient) of a tile are requested together
+  // with its input halo, one whole tile ahead of their use.
+  constexpr int ITER = G::ITER;
+  floatx4 pre_rv[ITER][MTW][NT], pre_xv[ITER][MTW][NT];
   floatx4 pf[G::NPF];
   unsigned okbits = 0;
   auto load_tile = [&](int t) {
     const int n = t / bands;
     const int oy0 = (t - n * bands) * TH;
     const int base_row = UPS ? (oy0 >> 1) : oy0 * S - a.pad;
+    {
+      const long long obase = ((long long)(n * a.Ho + oy0) * TW) * a.Cout;
+#pragma unroll
+      for (int it = 0; it < ITER; ++it)
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+          const long long oo = obase + (long long)((wave * MTW + it * 4 * MTW + i) * 16) * a.Cout + lane_o;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            pre_rv[it][i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+            pre_xv[it][i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (!(a.debug_skip & 4)) {
+              if (want_res) pre_rv[it][i][j] = *reinterpret_cast<const floatx4*>(a.res + oo + j * 16);
+              if (BWD) {
+                pre_xv[it][i][j] = *reinterpret_cast<const floatx4*>(a.mask_src + oo + j * 16);
+                if (a.extra) pre_rv[it][i][j] = *reinterpret_cast<const floatx4*>(a.extra + oo + j * 16);
+              }
+            }
+          }
+        }
+    }
     const float* in0 = a.in + ((long long)(n * a.H + base_row) * a.W) * CP;
     okbits = 0;
 #pragma unroll
@@ -221,21 +253,28 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_band_kernel(ConvFpropArgs a
 #pragma unroll
   for (int j = 0; j < NT; ++j) { st1[j] = floatx4{0.f, 0.f, 0.f, 0.f}; st2[j] = floatx4{0.f, 0.f, 0.f, 0.f}; }
 
-  // lane-constant parts of the LDS pixel address and of the output offset (pixel l15 of an m-tile)
-  const int lane_a = (((l15 / TW) * S) * LW + (l15 % TW) * S) * CPP + 4 * q;
-  const int lane_o = l15 * a.Cout + z * NT * 16 + 4 * q;
-  const bool want_res = !BWD && ((a.res_mode == RES_IDENT) || (a.res_mode == RES_BNRELU));
-
   for (; t < total_tiles; t += gpz) {
     const int n = t / bands;
     const int oy0 = (t - n * bands) * TH;
     const long long obase = ((long long)(n * a.Ho + oy0) * TW) * a.Cout;
 
     write_tile();
+    floatx4 cur_rv[ITER][MTW][NT], cur_xv[ITER][MTW][NT];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it)
+#pragma unroll
+      for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          cur_rv[it][i][j] = pre_rv[it][i][j];
+          cur_xv[it][i][j] = pre_xv[it][i][j];
+        }
     __syncthreads();
     if (t + gpz < total_tiles) load_tile(t + gpz);   // in flight during the MFMA phase
 
-    for (int mb = wave * MTW; mb < G::N_MT; mb += 4 * MTW) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int mb = wave * MTW + it * 4 * MTW;
       floatx4 acc[MTW][NT];
       floatx4 rv[MTW][NT], xv[MTW][NT];
       int aoff[MTW];
@@ -248,16 +287,8 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_band_kernel(ConvFpropArgs a
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-          rv[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-          xv[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-          // epilogue operands are requested now and consumed after the MFMA loop
-          if (!(a.debug_skip & 4)) {
-            if (want_res) rv[i][j] = *reinterpret_cast<const floatx4*>(a.res + ooff[i] + j * 16);
-            if (BWD) {
-              xv[i][j] = *reinterpret_cast<const floatx4*>(a.mask_src + ooff[i] + j * 16);
-              if (a.extra) rv[i][j] = *reinterpret_cast<const floatx4*>(a.extra + ooff[i] + j * 16);
-            }
-          }
+          rv[i][j] = cur_rv[it][i][j];
+          xv[i][j] = cur_xv[it][i][j];
         }
       }
 

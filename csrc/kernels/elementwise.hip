@@ -184,8 +184,21 @@ __global__ __launch_bounds__(256) void col_sum_kernel(ColSumArgs a) {
   __syncthreads();
   const long long total = a.n_rows * a.C;
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
-    atomicAdd(&red[(int)(i % a.C)], a.x[i]);
+  const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int C4 = a.C >> 2;
+  if ((a.C & 3) == 0 && (stride % C4) == 0) {
+    // every thread keeps one group of four channels across its grid-stride loop: 16-byte loads,
+    // register accumulation, one LDS atomic per channel at the end
+    const floatx4* x4 = reinterpret_cast<const floatx4*>(a.x);
+    const long long n4 = total >> 2;
+    floatx4 s = {0.f, 0.f, 0.f, 0.f};
+    for (long long i = gtid; i < n4; i += stride) s += x4[i];
+    const int c = (int)(gtid % C4) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(&red[c + e], s[e]);
+  } else {
+    for (long long i = gtid; i < total; i += stride) atomicAdd(&red[(int)(i % a.C)], a.x[i]);
+  }
   __syncthreads();
   for (int c = threadIdx.x; c < a.C; c += blockDim.x)
     if (red[c] != 0.f) atomicAdd(&a.out[c], red[c]);
@@ -313,8 +326,8 @@ void dropout_apply(const DropoutArgs& a, hipStream_t stream) {
 }
 void col_sum(const ColSumArgs& a, hipStream_t stream) {
   long long total = a.n_rows * a.C;
-  int blocks = flat_blocks(total);
-  if (blocks > 256) blocks = 256;
+  int blocks = flat_blocks(total >> 2);
+  if (blocks > 1024) blocks = 1024;
   launch("col_sum", col_sum_kernel, dim3(blocks), dim3(256), a.C * sizeof(float), stream, a);
 }
 void zero_count(const ZeroFracArgs& a, hipStream_t stream) {
