@@ -65,7 +65,7 @@ def stamps(run):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    print(f"batch {B}; columns: full | no-MFMA | no-input-loads | no-epilogue-mem | only-MFMA(6) | nothing(7) | full-without-stats-flush(8) | nothing-at-all(15)")
+    print(f"batch {B}; columns: full | no-MFMA | no-input-loads | no-epilogue-mem | only-MFMA(6) | nothing(7) | full-without-stats-flush(8) | nothing-at-all(15) | ping-pong kernel(64)")
     for (h, cin, cout, s) in SHAPES:
         ho = h // s
         x = torch.randn(B, h, h, cin, device="cuda")
@@ -80,7 +80,7 @@ def main():
         kw = dict(res_mode=nv.RES_IDENT, res=res) if res is not None else {}
         flops = 2.0 * B * ho * ho * cout * 9 * cin
         row = []
-        for skip in (0, 1, 2, 4, 6, 7, 8, 15):
+        for skip in (0, 1, 2, 4, 6, 7, 8, 15, 64):
             t = time_program(lambda: nv.conv_fprop(x, wpk, ks=3, cout=cout, stride=s, in_bn=bn, out=y, out_sums=sums,
                                                    debug_skip=skip, **kw))
             row.append(t)

@@ -26,7 +26,7 @@ struct ConvFpropArgs {
   int stride;                    // 1 or 2 (must match the template instance)
   int upsample;                  // 1: `in` is read as if zero-upsampled by 2 (stride-2 dgrad)
   int nt_total;                  // 16-channel output tiles in the packed filter (= ceil(Cout/16))
-  int debug_skip;                // timing experiments only: 1 = no MFMA, 2 = no input loads, 4 = no epilogue memory traffic, 8 = no statistics flush
+  int debug_skip;                // timing experiments only: 1 = no MFMA, 2 = no input loads, 4 = no epilogue memory traffic, 8 = no statistics flush; 64 = force the ping-pong kernel (tests)
   unsigned long long* dbg_stamps;  // timing experiments only: [blocks][16] wall-clock stamps of thread 0 (nullable)
   // prologue
   int in_mode;
@@ -51,6 +51,8 @@ struct ConvFpropArgs {
 size_t conv_fprop(const ConvFpropArgs& a, int ks, hipStream_t stream);
 // Compile-time band-geometry variant for the 3x3 ResNet shapes; returns 0 when the shape is not covered.
 size_t conv_fprop_band(const ConvFpropArgs& a, int ks, hipStream_t stream);
+// 8-wave ping-pong variant of the stride-1 band kernel (two wave groups half a period apart); 0 = not covered.
+size_t conv_fprop_pp(const ConvFpropArgs& a, int ks, hipStream_t stream);
 // Parity-decomposed data gradient of a 3x3 stride-2 layer (the `upsample` call); 0 = not covered.
 size_t conv_dgrad_s2(const ConvFpropArgs& a, int ks, hipStream_t stream);
 // Picks (TH, TW, tiles, cout split) for the given problem; fills the tiling fields of `a`.

@@ -398,6 +398,16 @@ size_t conv_fprop(const ConvFpropArgs& a_in, int ks, hipStream_t stream) {
     if (a_in.upsample) {
       if (size_t r = conv_dgrad_s2(a_in, ks, stream)) return r;
     }
+    // The 8-wave ping-pong variant measures the same as the band kernel standalone (60.6 vs 64.7,
+    // 49.4 vs 49.0, 49.4 vs 49.2 us at batch 1024) and, owning a whole CU, it cannot share the CU
+    // with the filter-gradient kernel on the side stream (3.45 vs 3.06 ms/step): opt-in only.
+    static const bool pp_on = [] {
+      const char* e = getenv("DTF_CONV_PP");
+      return e && e[0] == '1';
+    }();
+    if (pp_on || (a_in.debug_skip & 64)) {
+      if (size_t r = conv_fprop_pp(a_in, ks, stream)) return r;
+    }
     if (size_t r = conv_fprop_band(a_in, ks, stream)) return r;
   }
   if (a_in.TH <= 0 && persist_enabled()) {

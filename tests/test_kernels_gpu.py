@@ -146,6 +146,59 @@ def test_conv_dgrad_stride2_mask_epilogue(shape, with_extra):
     close(gt[cin:], (want * xhat).reshape(-1, cin).double().sum(0), 1e-4)
 
 
+@pytest.mark.parametrize("shape", [(5, 32, 16), (7, 16, 32), (9, 8, 64), (64, 8, 64)])
+@pytest.mark.parametrize("res_mode", ["ident", "bnrelu", "none"])
+def test_conv_pingpong_forward(shape, res_mode):
+    # 8-wave ping-pong kernel, forced: odd tile counts leave one wave group with fewer tiles
+    b, h, c = shape
+    x = rnd(b, h, h, c, scale=1.5) + 0.1
+    gamma, beta = rnd(c).abs() + 0.5, rnd(c, scale=0.3)
+    wt = rnd(3, 3, c, c, scale=0.1)
+    a = torch.relu(ref.batch_norm(x, gamma, beta))
+    want = ref.conv2d_same(a, wt, 1)
+    kw = {}
+    if res_mode == "ident":
+        res = rnd(b, h, h, c, seed=31)
+        want = want + res
+        kw = dict(res_mode=nv.RES_IDENT, res=res)
+    elif res_mode == "bnrelu":
+        res = rnd(b, h, h, c, seed=31)
+        g2, b2 = rnd(c, seed=32).abs() + 0.5, rnd(c, scale=0.3, seed=33)
+        want = want + torch.relu(ref.batch_norm(res, g2, b2))
+        kw = dict(res_mode=nv.RES_BNRELU, res=res, res_bn=bn_state_for(res, g2, b2))
+    sums = nv.new_stats(c, DEV)
+    got = nv.conv_fprop(x, nv.pack_weights(wt), ks=3, cout=c, in_bn=bn_state_for(x, gamma, beta), out_sums=sums, debug_skip=64, **kw)
+    close(got, want)
+    flat = want.reshape(-1, c).double()
+    tot = nv.stats_total(sums)
+    close(tot[:c], flat.sum(0), 1e-5)
+    close(tot[c:], (flat * flat).sum(0), 1e-5)
+
+
+@pytest.mark.parametrize("shape", [(5, 32, 16), (7, 16, 32), (9, 8, 64)])
+@pytest.mark.parametrize("with_extra", [False, True])
+def test_conv_pingpong_masked_dgrad(shape, with_extra):
+    b, h, c = shape
+    x_pre = rnd(b, h, h, c, scale=1.5)
+    gamma, beta = rnd(c).abs() + 0.5, rnd(c, scale=0.3)
+    wt = rnd(3, 3, c, c, scale=0.1)
+    a = torch.relu(ref.batch_norm(x_pre, gamma, beta)).requires_grad_(True)
+    y = ref.conv2d_same(a, wt, 1)
+    dy = rnd(*y.shape, seed=41)
+    extra = rnd(b, h, h, c, seed=43) if with_extra else None
+    (da,) = torch.autograd.grad(y, a, dy)
+    want = torch.where(ref.batch_norm(x_pre, gamma, beta) > 0, da + (extra if with_extra else 0), torch.zeros_like(da))
+    gs = nv.new_stats(c, DEV)
+    got = nv.conv_fprop(dy, nv.pack_weights(wt, flip=True), ks=3, cout=c, pad=1, out_hw=(h, h), epi_mode=nv.EPI_MASK,
+                        mask_src=x_pre, mask_bn=bn_state_for(x_pre, gamma, beta), extra=extra, out_sums=gs, debug_skip=64)
+    close(got, want)
+    mean, var = ref.batch_moments(x_pre)
+    xhat = (x_pre - mean) * torch.rsqrt(var + ref.BN_EPSILON)
+    gt = nv.stats_total(gs)
+    close(gt[:c], want.reshape(-1, c).double().sum(0), 1e-4)
+    close(gt[c:], (want * xhat).reshape(-1, c).double().sum(0), 1e-4)
+
+
 def test_conv_dgrad_mask_epilogue():
     b, h, w, cin, cout = 4, 16, 16, 32, 32
     x_pre = rnd(b, h, w, cin, scale=1.5)          # BN input of the layer below
