@@ -95,4 +95,35 @@ size_t conv_wgrad(ConvWgradArgs a, int ks, hipStream_t stream);
 // Band-tiled persistent variant for the 3x3 ResNet shapes; returns 0 when the shape is not covered.
 size_t conv_wgrad_band(const ConvWgradArgs& a, int ks, hipStream_t stream);
 
+
+// Whole backward pass of one stride-1 3x3 layer y = conv(relu(bn(x)), W) in one kernel:
+//   g   = 1[bn(x) > 0] * (conv(dy, W') + extra)      (gradient at the BatchNorm output, W' = flipped/transposed W)
+//   gsums += (sum g, sum g * xhat)                    (per-XCD statistic slots)
+//   dw  += sum_p relu(bn(x))[p + tap - 1] * dy[p]      (into the gradient copy of the block's XCD)
+struct ConvBwdFusedArgs {
+  const float* dy;       // [B,H,W,C]
+  const float* x;        // [B,H,W,C] the layer's (pre-BatchNorm) input
+  const float* wpk_t;    // data-gradient packing of W (pack_conv_weights with transpose_flip = 1)
+  float* g;              // [B,H,W,C]
+  float* dw;             // [3,3,C,C] HWIO, copy 0 of kStatSlots copies
+  long long dw_slot_stride;
+  BnRef bn;              // BatchNorm of x
+  double* gsums;         // [kStatSlots][2*C], nullable
+  const float* extra;    // [B,H,W,C] gradient added before masking, nullable
+  int B, H, W, C;
+  // Optional BatchNorm-backward prologue: `dy` then holds the masked gradient g' at the output of
+  // the BatchNorm that follows this layer's convolution, and the kernel reads
+  //     dy_eff = gamma*rstd * (g' - mean(g') - xhat(y) * mean(g'*xhat(y)))
+  // while staging, from g', the convolution output y (`dy_x`), that BatchNorm's statistics
+  // (`dy_bn`) and its backward sums (`dy_gsums`): the BatchNorm input gradient is never written
+  // to memory. Block 0 also writes that BatchNorm's dgamma / dbeta.
+  const float* dy_x;       // nullable = no prologue
+  BnRef dy_bn;
+  const double* dy_gsums;  // [kStatSlots][2*C]
+  float* dy_dgamma;        // [C], nullable
+  float* dy_dbeta;         // [C], nullable
+};
+bool conv_bwd_fused_supported(int B, int H, int W, int C);
+size_t conv_bwd_fused(const ConvBwdFusedArgs& a, hipStream_t stream);
+
 }  // namespace dtf

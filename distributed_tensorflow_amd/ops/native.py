@@ -286,6 +286,56 @@ def conv_wgrad(
     return dw
 
 
+def conv_bwd_fused_supported(x: torch.Tensor) -> bool:
+    b, h, w_, c = x.shape
+    return bool(hip().conv_bwd_fused_supported(b, h, w_, c))
+
+
+def conv_bwd_fused(dy, x, bn: BnState, wpk_t, dw, gsums, *, slot_stride: int = 0, extra=None, out=None,
+                   dy_bn=None, dy_dgamma=None, dy_dbeta=None):
+    """Backward of y = conv3x3(relu(bn(x)), W), stride 1, in one kernel: returns the masked data
+    gradient g, adds (sum g, sum g*xhat) to `gsums` and the filter gradient to `dw`
+    (see csrc/kernels/conv.h: ConvBwdFusedArgs).
+
+    dy_bn = (y, BnState of y, backward sums of that BatchNorm): `dy` is then the masked gradient
+    at the output of the BatchNorm that follows the convolution, and the BatchNorm input gradient
+    is formed on the fly; dy_dgamma / dy_dbeta receive that BatchNorm's parameter gradients."""
+    require()
+    b, h, w_, c = x.shape
+    if tuple(dy.shape) != (b, h, w_, c) or tuple(dw.shape) != (3, 3, c, c) or bn.channels != c:
+        raise ValueError("conv_bwd_fused: shape mismatch")
+    if wpk_t.numel() != 9 * (c // 16) * (c // 16) * 256 or gsums.numel() != STAT_SLOTS * 2 * c:
+        raise ValueError("conv_bwd_fused: packed filter / statistics block have the wrong size")
+    if slot_stride:
+        last = (dw.storage_offset() + (STAT_SLOTS - 1) * slot_stride + dw.numel()) * 4
+        if slot_stride < dw.numel() or last > dw.untyped_storage().nbytes():
+            raise ValueError("conv_bwd_fused: the slot copies do not fit dw's storage")
+    if out is None:
+        out = torch.empty_like(x)
+    elif tuple(out.shape) != (b, h, w_, c):
+        raise ValueError("conv_bwd_fused: out has the wrong shape")
+    d = dict(dy=_chk(dy, "dy"), x=_chk(x, "x"), wpk_t=_chk(wpk_t, "wpk_t"), g=_chk(out, "g"), dw=_chk(dw, "dw"),
+             dw_slot_stride=slot_stride, bn=bn.ref(), gsums=_chk(gsums, "gsums", torch.float64), B=b, H=h, W=w_, C=c)
+    if extra is not None:
+        if tuple(extra.shape) != (b, h, w_, c):
+            raise ValueError("extra must match the output shape")
+        d["extra"] = _chk(extra, "extra")
+    if dy_bn is not None:
+        y, ybn, ygs = dy_bn
+        if tuple(y.shape) != (b, h, w_, c) or ybn.channels != c or ygs.numel() != STAT_SLOTS * 2 * c:
+            raise ValueError("conv_bwd_fused: dy_bn operands have the wrong shape")
+        d["dy_x"] = _chk(y, "dy_x")
+        d["dy_bn"] = ybn.ref()
+        d["dy_gsums"] = _chk(ygs, "dy_gsums", torch.float64)
+        for key, t in (("dy_dgamma", dy_dgamma), ("dy_dbeta", dy_dbeta)):
+            if t is not None:
+                if t.numel() != c:
+                    raise ValueError(f"{key} must have C elements")
+                d[key] = _chk(t, key)
+    hip().conv_bwd_fused(d, stream())
+    return out
+
+
 # ----------------------------------------------------------------------------- batch norm
 def bn_stats(x: torch.Tensor, sums: Optional[torch.Tensor] = None) -> torch.Tensor:
     require()

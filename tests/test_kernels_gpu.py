@@ -199,6 +199,73 @@ def test_conv_pingpong_masked_dgrad(shape, with_extra):
     close(gt[c:], (want * xhat).reshape(-1, c).double().sum(0), 1e-4)
 
 
+@pytest.mark.parametrize("shape", [(5, 32, 16), (7, 16, 32), (9, 8, 64), (70, 8, 64)])
+@pytest.mark.parametrize("with_extra", [False, True])
+def test_conv_bwd_fused(shape, with_extra):
+    # one kernel: masked data gradient + BatchNorm-backward sums + filter gradient (per-XCD copies)
+    b, h, c = shape
+    x_pre = rnd(b, h, h, c, scale=1.5) + 0.1
+    gamma, beta = rnd(c).abs() + 0.5, rnd(c, scale=0.3)
+    wt = rnd(3, 3, c, c, scale=0.1).requires_grad_(True)
+    a = torch.relu(ref.batch_norm(x_pre, gamma, beta)).requires_grad_(True)
+    y = ref.conv2d_same(a, wt, 1)
+    dy = rnd(*y.shape, seed=51)
+    extra = rnd(b, h, h, c, seed=53) if with_extra else None
+    da, dw_want = torch.autograd.grad(y, (a, wt), dy)
+    want = torch.where(ref.batch_norm(x_pre, gamma, beta) > 0, da + (extra if with_extra else 0), torch.zeros_like(da))
+    n = dw_want.numel()
+    slots = torch.zeros(nv.STAT_SLOTS, n + 64, device=DEV)
+    gs = nv.new_stats(c, DEV)
+    assert nv.conv_bwd_fused_supported(x_pre)
+    got = nv.conv_bwd_fused(dy, x_pre, bn_state_for(x_pre, gamma, beta), nv.pack_weights(wt.detach(), flip=True),
+                            slots[0, :n].view(3, 3, c, c), gs, slot_stride=n + 64, extra=extra)
+    close(got, want)
+    assert slots[:, n:].abs().max().item() == 0
+    close(slots[:, :n].sum(0).view(dw_want.shape), dw_want)
+    mean, var = ref.batch_moments(x_pre)
+    xhat = (x_pre - mean) * torch.rsqrt(var + ref.BN_EPSILON)
+    gt = nv.stats_total(gs)
+    close(gt[:c], want.reshape(-1, c).double().sum(0), 1e-4)
+    close(gt[c:], (want * xhat).reshape(-1, c).double().sum(0), 1e-4)
+
+
+@pytest.mark.parametrize("shape", [(5, 32, 16), (6, 16, 32), (9, 8, 64)])
+def test_conv_bwd_fused_with_bn_backward_prologue(shape):
+    # x -> bn1/relu -> conv1 -> y -> bn2/relu -> conv2 -> z. The backward of conv1 takes the masked
+    # gradient at bn2's output and applies bn2's backward while staging it.
+    b, h, c = shape
+    x = rnd(b, h, h, c, scale=1.5) + 0.1
+    g1, b1 = rnd(c).abs() + 0.5, rnd(c, scale=0.3)
+    g2 = (rnd(c, seed=61).abs() + 0.5).requires_grad_(True)
+    b2 = rnd(c, scale=0.3, seed=62).requires_grad_(True)
+    w1 = rnd(3, 3, c, c, scale=0.1).requires_grad_(True)
+    w2 = rnd(3, 3, c, c, scale=0.1, seed=63)
+    a1 = torch.relu(ref.batch_norm(x, g1, b1)).requires_grad_(True)
+    y = ref.conv2d_same(a1, w1, 1)
+    u2 = ref.batch_norm(y, g2, b2)
+    u2.retain_grad()
+    z = ref.conv2d_same(torch.relu(u2), w2, 1)
+    dz = rnd(*z.shape, seed=64)
+    da1, dw1, dg2, db2 = torch.autograd.grad(z, (a1, w1, g2, b2), dz, retain_graph=True)
+    (du2,) = torch.autograd.grad(z, u2, dz)                      # already masked by relu'
+    want_g = torch.where(ref.batch_norm(x, g1, b1) > 0, da1, torch.zeros_like(da1))
+    yd = y.detach()
+    mean, var = ref.batch_moments(yd)
+    yhat = (yd - mean) * torch.rsqrt(var + ref.BN_EPSILON)
+    gs2 = nv.stats_from_totals(torch.cat([du2.reshape(-1, c).double().sum(0), (du2 * yhat).reshape(-1, c).double().sum(0)]))
+    n = dw1.numel()
+    slots = torch.zeros(nv.STAT_SLOTS, n, device=DEV)
+    gs1 = nv.new_stats(c, DEV)
+    dgam, dbet = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    got = nv.conv_bwd_fused(du2.contiguous(), x, bn_state_for(x, g1, b1), nv.pack_weights(w1.detach(), flip=True),
+                            slots[0].view(3, 3, c, c), gs1, slot_stride=n,
+                            dy_bn=(yd, bn_state_for(yd, g2.detach(), b2.detach()), gs2), dy_dgamma=dgam, dy_dbeta=dbet)
+    close(got, want_g, 2e-4)
+    close(slots.sum(0).view(dw1.shape), dw1, 2e-4)
+    close(dgam, dg2, 1e-4)
+    close(dbet, db2, 1e-4)
+
+
 def test_conv_dgrad_mask_epilogue():
     b, h, w, cin, cout = 4, 16, 16, 32, 32
     x_pre = rnd(b, h, w, cin, scale=1.5)          # BN input of the layer below
