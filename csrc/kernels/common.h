@@ -67,6 +67,48 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Block-level flush of per-channel statistics held as per-lane partials in the swapped-operand
+// accumulator layout (lane (q, l15), register r <-> channel 16*j + 4*q + r, pixel l15): reduce over
+// the 16 pixel lanes, park one row per wave in `scratch` (WAVES * 2 * NT*16 floats that nobody
+// reads any more), and let 2*NT*16 threads add the rows in wave order before the fp64 atomic into
+// this workgroup's slot. Every step has a fixed order, so the block's contribution is bit-identical
+// from run to run: with order-dependent float atomics here the batch statistics differed in their
+// last bits between runs, enough to flip the ReLU mask of an activation within rounding of zero.
+template <int NT, int WAVES>
+__device__ __forceinline__ void block_stat_flush(float* scratch, const floatx4 (&st1)[NT], const floatx4 (&st2)[NT],
+                                                 double* sums, int C, int c_first) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int q = lane >> 4, l15 = lane & 15;
+  __syncthreads();   // scratch may alias tile buffers that other waves were still reading
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v1 = st1[j][r], v2 = st2[j][r];
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        v1 += __shfl_xor(v1, off);
+        v2 += __shfl_xor(v2, off);
+      }
+      if (l15 == 0) {
+        scratch[(wave * 2 + 0) * NT * 16 + j * 16 + 4 * q + r] = v1;
+        scratch[(wave * 2 + 1) * NT * 16 + j * 16 + 4 * q + r] = v2;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * NT * 16) {
+    const int which = tid / (NT * 16);
+    const int c = tid - which * (NT * 16);
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) s += (double)scratch[(w * 2 + which) * NT * 16 + c];
+    if (c_first + c < C) atomicAdd(&stat_slot(sums, C)[which * C + c_first + c], s);
+  }
+}
+
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace dtf

@@ -361,24 +361,8 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
     __syncthreads();   // all waves are done with this band's LDS tiles
   }
 
-  // ---- statistics ---------------------------------------------------------------------------------
-  if (a.gsums) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v1 = st1[j][r], v2 = st2[j][r];
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-          v1 += __shfl_xor(v1, off);
-          v2 += __shfl_xor(v2, off);
-        }
-        if (l15 == 0) {
-          atomicAdd(&s_stat[j * 16 + 4 * q + r], v1);
-          atomicAdd(&s_stat[XC + j * 16 + 4 * q + r], v2);
-        }
-      }
-  }
+  // ---- statistics (the filter slice in LDS is no longer needed: its space parks the wave rows) ------
+  if (a.gsums) block_stat_flush<NT, 4>(s_w, st1, st2, a.gsums, C, c0);
   // ---- filter gradient flush: accumulators -> LDS, sum the pixel-split partials, coalesced atomics ----
   constexpr int RS = G::RED_STRIDE;
   float* s_red = smem;   // [WX][9][XC][RS]; the tile buffers are free (barrier above)
@@ -388,11 +372,6 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
     for (int r = 0; r < 4; ++r)
       s_red[((wx * 9 + tap) * XC + ci_t * 16 + 4 * q + r) * RS + co_t * 16 + l15] = accw[tap][r];
   __syncthreads();
-  if (a.gsums && tid < 2 * XC) {
-    const int which = tid / XC;
-    const int c = tid - which * XC;
-    atomicAdd(&stat_slot(a.gsums, C)[which * C + c0 + c], (double)s_stat[tid]);
-  }
   float* dw = a.dw + (size_t)(blockIdx.x & (kStatSlots - 1)) * a.dw_slot_stride;
   for (int e = tid; e < 9 * XC * C; e += 256) {
     const int col = e % C;

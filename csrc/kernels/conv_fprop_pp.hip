@@ -371,28 +371,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(ConvFpropArgs a) 
   }
 
   if (a.out_sums) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v1 = st1[j][r], v2 = st2[j][r];
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-          v1 += __shfl_xor(v1, off);
-          v2 += __shfl_xor(v2, off);
-        }
-        if (l15 == 0) {
-          atomicAdd(&s_stat[j * 16 + 4 * q + r], v1);
-          atomicAdd(&s_stat[NT * 16 + j * 16 + 4 * q + r], v2);
-        }
-      }
-    }
-    __syncthreads();
-    if (tid < 2 * NT * 16) {
-      const int which = tid / (NT * 16);
-      const int c = tid - which * (NT * 16);
-      atomicAdd(&stat_slot(a.out_sums, a.Cout)[which * a.Cout + z * NT * 16 + c], (double)s_stat[tid]);
-    }
+    block_stat_flush<NT, 8>(smem, st1, st2, a.out_sums, a.Cout, z * NT * 16);
   }
 }
 
