@@ -47,10 +47,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
   const int tile_px = a.TH * a.TW;
   const int px_pad = (tile_px + 3) & ~3;
 
+  // The tile area (input halo + output-gradient tile) doubles as the flush scratch and is at
+  // least one tap's worth of it: WX * CI_T*16 rows of CO_B + 4 floats.
+  int tile_floats = round_up4(LH * LW * CPP) + px_pad * COP;
+  if (tile_floats < WX * CI_T * 16 * (CO_B + 4)) tile_floats = WX * CI_T * 16 * (CO_B + 4);
   float* s_in = smem;                                  // [LH*LW][CPP]
   float* s_do = s_in + round_up4(LH * LW * CPP);       // [px_pad][COP]
-  float* s_bn = s_do + px_pad * COP;                   // scale[CP], shift[CP]
-  float* s_red = s_bn + 2 * CP;                        // [CI_T*16][CO_B] flush scratch
+  float* s_bn = smem + tile_floats;                    // scale[CP], shift[CP]
 
   const int co_blk0 = blockIdx.y * CO_B;
   const int tiles_img = a.tiles_y * a.tiles_x;
@@ -181,46 +184,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
 
   if (a.debug_skip & 4) return;
   float* dw = a.dw + (size_t)(blockIdx.x & (kStatSlots - 1)) * a.dw_slot_stride;
-  // ---- flush: per tap, gather the block's [CI_T*16][CO_B] slab in LDS, then coalesced atomics
-#pragma unroll
-  for (int tap = 0; tap < TAPS; ++tap) {  // unrolled: acc[][] must be indexed statically
+  // ---- flush: groups of taps go through the (now free) tile area of LDS in one pass each: every
+  // wave parks its accumulators, one barrier, then all threads add the pixel-split partials and
+  // issue coalesced fp32 atomics that nobody waits for. A group is as many taps as fit.
+  constexpr int ROWS = CI_T * 16;
+  constexpr int RS = CO_B + 4;            // padded row: the four q groups of a wave hit different banks
+  float* s_fl = smem;
+  int tg = tile_floats / (WX * ROWS * RS);
+  if (tg > TAPS) tg = TAPS;
+  if (tg < 1) tg = 1;                     // the launcher sizes LDS for at least one tap
+  for (int tap0 = 0; tap0 < TAPS; tap0 += tg) {
     __syncthreads();
-    if (WX > 1) {
-      for (int i = tid; i < CI_T * 16 * CO_B; i += 256) s_red[i] = 0.f;
-      __syncthreads();
-    }
 #pragma unroll
-    for (int k = 0; k < PPW; ++k) {
-      const int pr = wp * PPW + k;
-      const int ci_t = pr / CO_T, co_t = pr % CO_T;
-      const floatx4 v = acc[tap][k];
+    for (int tap = 0; tap < TAPS; ++tap) {  // unrolled: acc[][] must be indexed statically
+      if (tap < tap0 || tap >= tap0 + tg) continue;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float* dst = s_red + (ci_t * 16 + 4 * q + r) * CO_B + co_t * 16 + l15;
-        if (WX > 1)
-          atomicAdd(dst, v[r]);
-        else
-          *dst = v[r];
+      for (int k = 0; k < PPW; ++k) {
+        const int pr = wp * PPW + k;
+        const int ci_t = pr / CO_T, co_t = pr % CO_T;
+        const floatx4 v = acc[tap][k];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          s_fl[((wx * tg + (tap - tap0)) * ROWS + ci_t * 16 + 4 * q + r) * RS + co_t * 16 + l15] = v[r];
       }
     }
     __syncthreads();
-    for (int i = tid; i < CI_T * 16 * CO_B; i += 256) {
-      const int row = i / CO_B;
-      const int co = co_blk0 + (i - row * CO_B);
+    const int n_here = (TAPS - tap0 < tg ? TAPS - tap0 : tg) * ROWS * CO_B;
+    for (int i = tid; i < n_here; i += 256) {
+      const int col = i % CO_B;
+      const int row = (i / CO_B) % ROWS;
+      const int tl = i / (CO_B * ROWS);
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WX; ++w) v += s_fl[((w * tg + tl) * ROWS + row) * RS + col];
+      const int co = co_blk0 + col;
       int tap_g, ci;
       if (CP >= 16) {
-        tap_g = tap;
+        tap_g = tap0 + tl;
         ci = row;
       } else {
         tap_g = 4 * (row >> 4) + ((row & 15) >> 2);
         ci = row & 3;
       }
-      if (tap_g < KS * KS && ci < a.Cin && co < a.Cout) {
-        const float v = s_red[i];
-        if (v != 0.f) atomicAdd(dw + ((size_t)tap_g * a.Cin + ci) * a.Cout + co, v);
-      }
+      if (tap_g < KS * KS && ci < a.Cin && co < a.Cout && v != 0.f) atomicAdd(dw + ((size_t)tap_g * a.Cin + ci) * a.Cout + co, v);
     }
-    if (tap < 9) DTF_STAMP(4 + tap);
   }
   DTF_STAMP(15);
 #undef DTF_STAMP
@@ -234,7 +241,12 @@ size_t launch_wgrad(const ConvWgradArgs& a, hipStream_t stream) {
   constexpr int CI_T = (CP >= 16) ? CP / 16 : (KS * KS + 3) / 4;
   const int LH = (a.TH - 1) * S + KS, LW = (a.TW - 1) * S + KS;
   const int px_pad = (a.TH * a.TW + 3) & ~3;
-  const size_t floats = (size_t)((LH * LW * CPP + 3) & ~3) + (size_t)px_pad * COP + 2 * CP + (size_t)CI_T * 16 * CO_B;
+  constexpr int PAIRS = CI_T * CO_T;
+  constexpr int WX = 4 / ((PAIRS % 4 == 0) ? 4 : ((PAIRS % 2 == 0) ? 2 : 1));
+  size_t tile_floats = (size_t)((LH * LW * CPP + 3) & ~3) + (size_t)px_pad * COP;
+  const size_t one_tap = (size_t)WX * CI_T * 16 * (CO_B + 4);   // flush scratch for one tap (see the kernel)
+  if (tile_floats < one_tap) tile_floats = one_tap;
+  const size_t floats = tile_floats + 2 * CP;
   const size_t shmem = floats * sizeof(float);
   if (shmem > 160 * 1024) throw std::runtime_error("conv_wgrad: tile does not fit LDS");
   const int total_tiles = a.tiles_y * a.tiles_x * a.B;

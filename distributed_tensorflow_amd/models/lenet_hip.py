@@ -100,13 +100,23 @@ class LeNetHipStep(StepProgramBase):
                 nv.gemm(self.dh, a.param("fc1_weights"), trans_b=True, out=self.dp2)
                 da2 = nv.maxpool2x2_bwd(self.dp2.view(B, 7, 7, 64), self.arg2, self.p2, (B, 14, 14, 64), relu_mask=True)
                 self.da2 = da2
-                nv.conv_wgrad(self.p1, da2, a.grad("conv2_weights"), stride=1)
+                # filter gradients accumulate in per-XCD copies of the conv part of the arena
+                conv_end = a.offsets["fc1_weights"]
+                if not hasattr(self, "_wslots"):
+                    self._wslots = torch.zeros(nv.STAT_SLOTS, conv_end, device=self.device, dtype=torch.float32)
+
+                def slot_view(name):
+                    off, spec = a.offsets[name], a.spec(name)
+                    return self._wslots[0, off:off + spec.numel].view(spec.shape)
+
+                nv.conv_wgrad(self.p1, da2, slot_view("conv2_weights"), stride=1, slot_stride=conv_end)
                 nv.col_sum(da2.view(-1, 64), a.grad("conv2_biases"))
                 nv.conv_fprop(da2, self.wpk2_t, ks=5, cout=32, pad=2, out_hw=(14, 14), out=self.dp1)
                 da1 = nv.maxpool2x2_bwd(self.dp1, self.arg1, self.p1, (B, 28, 28, 32), relu_mask=True)
                 self.da1 = da1
-                nv.conv_wgrad(self.images, da1, a.grad("conv1_weights"), stride=1)
+                nv.conv_wgrad(self.images, da1, slot_view("conv1_weights"), stride=1, slot_stride=conv_end)
                 nv.col_sum(da1.view(-1, 32), a.grad("conv1_biases"))
+                nv.slot_reduce(a.grads, self._wslots, 0, conv_end)
                 self.bucket_ranges.append((0, lo))
                 p.mark_segment()
                 self._record_optimizer()
