@@ -1,9 +1,11 @@
 // fp32 GEMM on the exact-fp32 matrix cores (fully connected layers of LeNet).
 //
-// C[M,N] = op(A)[M,K] * op(B)[K,N] (+ bias[N]) (ReLU). 64x64 block tile, 16-deep k-step, four
+// C[M,N] = op(A)[M,K] * op(B)[K,N] (+ bias[N]) (ReLU). 64x64 block tile, 32-deep k-step, four
 // waves each owning a 32x32 quadrant as 2x2 MFMA 16x16x4 tiles. Both operand tiles are stored
 // k-contiguous in LDS ([row][k] and [col][k], rows padded by 4 floats) so that one
 // ds_read_b128 per operand feeds four MFMAs, using the same k-permutation as the conv kernels.
+// The global loads of k-step i+1 are issued into registers before the MFMAs of k-step i (with
+// batch-sized M a block walks few, latency-bound k-steps, so nothing else hides the latency).
 // Small-M problems (batch-sized M) are split along K across blocks to fill the 256 CUs; the
 // partial products are combined with fp32 atomics and bias/ReLU run as a second tiny pass.
 // (reference ops: tf.matmul in DistributedLeNet/src/mnist.py:136,145)
@@ -12,7 +14,8 @@
 namespace dtf {
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 16, LDT = BK + 4;
+constexpr int BM = 64, BN = 64, BK = 32, LDT = BK + 4;
+constexpr int EPT = BM * BK / 256;   // tile elements staged per thread and operand
 
 struct GemmKArgs {
   GemmArgs g;
@@ -38,40 +41,60 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmKArgs ka) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = floatx4{0, 0, 0, 0};
 
-  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-    // stage A tile [BM][BK] and B tile [BN][BK]; 1024 elements each, 4 per thread
+  float ra[EPT], rb[EPT];
+  auto fetch = [&](int k0) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < EPT; ++it) {
       const int e = tid + it * 256;
       {
         int r, kk;
-        if (a.trans_a) { r = e & 63; kk = e >> 6; } else { kk = e & 15; r = e >> 4; }
+        if (a.trans_a) { r = e & 63; kk = e >> 6; } else { kk = e & (BK - 1); r = e / BK; }
         const int m = m0 + r, k = k0 + kk;
         float v = 0.f;
         if (m < a.M && k < k_end) v = a.trans_a ? a.A[(size_t)k * a.lda + m] : a.A[(size_t)m * a.lda + k];
-        As[r * LDT + kk] = v;
+        ra[it] = v;
       }
       {
         int c, kk;
-        if (a.trans_b) { kk = e & 15; c = e >> 4; } else { c = e & 63; kk = e >> 6; }
+        if (a.trans_b) { kk = e & (BK - 1); c = e / BK; } else { c = e & 63; kk = e >> 6; }
         const int n = n0 + c, k = k0 + kk;
         float v = 0.f;
         if (n < a.N && k < k_end) v = a.trans_b ? a.B[(size_t)n * a.ldb + k] : a.B[(size_t)k * a.ldb + n];
-        Bs[c * LDT + kk] = v;
+        rb[it] = v;
       }
     }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < EPT; ++it) {
+      const int e = tid + it * 256;
+      int r, kk, c, kk2;
+      if (a.trans_a) { r = e & 63; kk = e >> 6; } else { kk = e & (BK - 1); r = e / BK; }
+      if (a.trans_b) { kk2 = e & (BK - 1); c = e / BK; } else { c = e & 63; kk2 = e >> 6; }
+      As[r * LDT + kk] = ra[it];
+      Bs[c * LDT + kk2] = rb[it];
+    }
+  };
+
+  if (k_begin < k_end) fetch(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+    commit();
     __syncthreads();
-    floatx4 av[2], bv[2];
+    if (k0 + BK < k_end) fetch(k0 + BK);   // in flight during the MFMAs
 #pragma unroll
-    for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const floatx4*>(&As[(wm + i * 16 + l15) * LDT + 4 * q]);
+    for (int kg = 0; kg < BK / 16; ++kg) {
+      floatx4 av[2], bv[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const floatx4*>(&Bs[(wn + j * 16 + l15) * LDT + 4 * q]);
+      for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const floatx4*>(&As[(wm + i * 16 + l15) * LDT + kg * 16 + 4 * q]);
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+      for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const floatx4*>(&Bs[(wn + j * 16 + l15) * LDT + kg * 16 + 4 * q]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = DTF_MFMA16(av[i][s], bv[j][s], acc[i][j]);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = DTF_MFMA16(av[i][s], bv[j][s], acc[i][j]);
+    }
     __syncthreads();
   }
 
