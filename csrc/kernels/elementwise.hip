@@ -326,8 +326,14 @@ void dropout_apply(const DropoutArgs& a, hipStream_t stream) {
 }
 void col_sum(const ColSumArgs& a, hipStream_t stream) {
   long long total = a.n_rows * a.C;
-  int blocks = flat_blocks(total >> 2);
-  if (blocks > 1024) blocks = 1024;
+  // few, fat blocks: every block ends with one atomic per column on the same C addresses, and
+  // same-address atomics serialise (~20 ns each), so 1024 blocks cost 20 us in the tail alone
+  // so the grid grows with the data (64 K floats per block) and stays between 32 and 1024 blocks
+  long long nb = total >> 16;
+  if (nb < 32) nb = 32;
+  if (nb > 1024) nb = 1024;
+  if (nb > flat_blocks(total >> 2)) nb = flat_blocks(total >> 2);
+  const int blocks = (int)nb;
   launch("col_sum", col_sum_kernel, dim3(blocks), dim3(256), a.C * sizeof(float), stream, a);
 }
 void zero_count(const ZeroFracArgs& a, hipStream_t stream) {
