@@ -214,8 +214,6 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
     s_co[XC + tid] = bet - m * sc;
     s_co[2 * XC + tid] = m;
     s_co[3 * XC + tid] = r;
-    s_stat[tid] = 0.f;
-    s_stat[XC + tid] = 0.f;
   }
   if (DYBN && tid < C) {
     const double inv = (double)a.dy_bn.inv_count;

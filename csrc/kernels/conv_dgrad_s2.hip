@@ -133,8 +133,6 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_kernel(ConvFpropArgs a) 
     s_ebn[NT * 16 + tid] = eb_b - m * sc;
     s_ebn[2 * NT * 16 + tid] = m;
     s_ebn[3 * NT * 16 + tid] = r;
-    s_stat[tid] = 0.f;
-    s_stat[NT * 16 + tid] = 0.f;
   }
 #pragma unroll
   for (int k = 0; k < G::NW; ++k)

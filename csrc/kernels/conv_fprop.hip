@@ -72,7 +72,6 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(ConvFpropArgs a) {
       s_bn[CP + tid] = sh;
     }
   }
-  if (tid < 2 * NT * 16) s_stat[tid] = 0.f;
 
   // ---- stage the filter slice (already in B-operand order) --------------------------
   {

@@ -228,8 +228,6 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_band_kernel(ConvFpropArgs a
     s_ebn[2 * NT * 16 + tid] = m;
     s_ebn[3 * NT * 16 + tid] = r;
     s_ebn[4 * NT * 16 + tid] = e_bias_v;
-    s_stat[tid] = 0.f;
-    s_stat[NT * 16 + tid] = 0.f;
   }
 #pragma unroll
   for (int k = 0; k < G::NW; ++k)

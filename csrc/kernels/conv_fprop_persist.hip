@@ -126,7 +126,6 @@ __global__ __launch_bounds__(256, (CP <= 16 && NT == 1) ? 3 : 2) void conv_fprop
     s_bn[tid] = sc;
     s_bn[CP + tid] = sh;
   }
-  if (tid < 2 * NT * 16) s_stat[tid] = 0.f;
   {
     const floatx4* wsrc = reinterpret_cast<const floatx4*>(a.wpk);
     floatx4* wdst = reinterpret_cast<floatx4*>(s_w);
