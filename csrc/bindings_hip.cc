@@ -94,9 +94,11 @@ PYBIND11_MODULE(_hip, m) {
     V(dw_slot_stride); a.bn = as_bn(d, "bn"); P(gsums, double); P(extra, const float);
     V(B); V(H); V(W); V(C);
     P(dy_x, const float); a.dy_bn = as_bn(d, "dy_bn"); P(dy_gsums, const double); P(dy_dgamma, float); P(dy_dbeta, float);
+    P(tile_counters, int);
     return conv_bwd_fused(a, as_stream(stream));
   });
   m.def("conv_bwd_fused_supported", &conv_bwd_fused_supported);
+  m.attr("BWD_TILE_COUNTERS") = (int)kBwdTileCounters;
   m.def("pack_multi", [](uint64_t params, uint64_t packed, uint64_t table, int n_entries, int total_blocks,
                          uint64_t stream) {
     PackMultiArgs a{reinterpret_cast<const float*>(params), reinterpret_cast<float*>(packed),

@@ -122,7 +122,14 @@ struct ConvBwdFusedArgs {
   const double* dy_gsums;  // [kStatSlots][2*C]
   float* dy_dgamma;        // [C], nullable
   float* dy_dbeta;         // [C], nullable
+  // Optional dynamic tile scheduling: kBwdTileCounters zeroed ints. A block takes its first two
+  // bands statically and every further one from the counter of its XCD (and channel split), so
+  // when some CUs are shared with another kernel (an all-reduce of an earlier gradient bucket, a
+  // neighbour process) the remaining blocks pick up the work instead of the grid waiting for the
+  // slow blocks' fixed share. nullptr = static striding.
+  int* tile_counters;
 };
+constexpr int kBwdTileCounters = 32;   // 8 XCDs x up to 4 channel splits
 bool conv_bwd_fused_supported(int B, int H, int W, int C);
 size_t conv_bwd_fused(const ConvBwdFusedArgs& a, hipStream_t stream);
 

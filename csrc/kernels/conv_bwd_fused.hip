@@ -200,7 +200,20 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
       if (tid + k * 256 < G::X_CHUNKS) *reinterpret_cast<floatx4*>(s_x + x_loff[k]) = pf_x[k];
   };
 
+  // Tile walk. Static: t, t + gpz, ... Dynamic (a.tile_counters): the first two tiles are the static
+  // ones; further tiles of XCD x are x + 8k with k handed out by that XCD's counter. Thread 0 asks
+  // for a tile one whole iteration before the block needs it and publishes it through LDS.
+  const int xcd = bid & 7;
+  int* ctr = a.tile_counters ? a.tile_counters + z * 8 + xcd : nullptr;
+  __shared__ int s_next_tile;
+  auto take_tile = [&]() -> int {   // thread 0 only
+    const int k = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 2 * (gpz >> 3);
+    return xcd + 8 * k;
+  };
   int t = jblk;
+  int t_next = t + gpz;
+  int r_fetch = total_tiles;        // thread 0: the tile after t_next
+  if (ctr && tid == 0) r_fetch = take_tile();
   if (t < total_tiles) load_band(t);
 
   if (co_thread) {
@@ -265,14 +278,17 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
     for (int tap = 0; tap < 9; ++tap) bf[tap] = bp[-((tap / 3) * LW + (tap % 3)) * CPP];
   };
 
-  for (; t < total_tiles; t += gpz) {
+  while (t < total_tiles) {
     const int n = t / bands;
     const int oy0 = (t - n * bands) * TH;
     const long long obase = ((long long)(n * a.H + oy0) * TW) * C;
 
     write_band();
+    if (ctr && tid == 0) s_next_tile = r_fetch;
     __syncthreads();
-    if (t + gpz < total_tiles) load_band(t + gpz);   // in flight during both MFMA phases
+    const int t_after = ctr ? s_next_tile : t_next + gpz;
+    if (ctr && tid == 0 && t_after < total_tiles) r_fetch = take_tile();   // lands during the MFMA phases
+    if (t_next < total_tiles) load_band(t_next);   // in flight during both MFMA phases
 
     // ---- data gradient: M = pixels, N = ci slice, K = taps x C --------------------------------------
 #pragma unroll
@@ -357,6 +373,8 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
       }
     }
     __syncthreads();   // all waves are done with this band's LDS tiles
+    t = t_next;
+    t_next = t_after;
   }
 
   // ---- statistics (the filter slice in LDS is no longer needed: its space parks the wave rows) ------

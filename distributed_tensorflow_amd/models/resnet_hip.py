@@ -140,6 +140,13 @@ class ResNetHipStep(StepProgramBase):
             self._d_c0 = torch.empty_like(self.c0)
             # stride-1 layers run data gradient + filter gradient + BatchNorm sums as ONE kernel
             self.fused_backward = os.environ.get("DTF_BWD_FUSED", "1") != "0"
+            # work counters of the fused backward kernels (dynamic band scheduling), one block of
+            # counters per layer, zeroed with the statistics at the start of every step. Opt-in:
+            # alone on the GPU the static walk is 3 % faster (3.06 vs 3.15 ms/step at batch 1024);
+            # dynamic hand-out is for CUs shared with a collective or another process.
+            self.dynamic_tiles = os.environ.get("DTF_DYNAMIC_TILES", "0") != "0"
+            self._tile_ctr = torch.zeros(2 * len(self.blocks) * nv.hip().BWD_TILE_COUNTERS, device=dev, dtype=torch.int32)
+            self._tile_ctr_used = 0
             # With separate filter-gradient kernels a side stream hides them behind the data-gradient
             # chain (1.40 -> 1.24 ms/step at batch 256); with the fused kernels only three filter
             # gradients remain and the second stream measures slightly slower (1.23 vs 1.19 ms).
@@ -261,6 +268,10 @@ class ResNetHipStep(StepProgramBase):
                 if dout_bn is not None:
                     y_t, ybn = dout_bn
                     kw = dict(dy_bn=(y_t, ybn.fwd, ybn.gsums), dy_dgamma=a.grad(ybn.gamma_name), dy_dbeta=a.grad(ybn.beta_name))
+                if self.dynamic_tiles:
+                    nctr = nv.hip().BWD_TILE_COUNTERS
+                    kw["tile_counters"] = self._tile_ctr[self._tile_ctr_used:self._tile_ctr_used + nctr]
+                    self._tile_ctr_used += nctr
                 return nv.conv_bwd_fused(dout, x, bn.fwd, self._wpk(conv.weight, True), dw_slot_view(conv.weight), bn.gsums,
                                          slot_stride=a.total, extra=extra, out=out, **kw)
             assert dout_bn is None
@@ -320,6 +331,8 @@ class ResNetHipStep(StepProgramBase):
         p.begin_record()
         try:
             nv.memset_zero(self.stats)
+            if self.training:
+                nv.memset_zero(self._tile_ctr)
             self._record_prologue()
             self._record_forward()
             if self.training:

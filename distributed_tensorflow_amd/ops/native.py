@@ -292,7 +292,7 @@ def conv_bwd_fused_supported(x: torch.Tensor) -> bool:
 
 
 def conv_bwd_fused(dy, x, bn: BnState, wpk_t, dw, gsums, *, slot_stride: int = 0, extra=None, out=None,
-                   dy_bn=None, dy_dgamma=None, dy_dbeta=None):
+                   dy_bn=None, dy_dgamma=None, dy_dbeta=None, tile_counters=None):
     """Backward of y = conv3x3(relu(bn(x)), W), stride 1, in one kernel: returns the masked data
     gradient g, adds (sum g, sum g*xhat) to `gsums` and the filter gradient to `dw`
     (see csrc/kernels/conv.h: ConvBwdFusedArgs).
@@ -332,6 +332,11 @@ def conv_bwd_fused(dy, x, bn: BnState, wpk_t, dw, gsums, *, slot_stride: int = 0
                 if t.numel() != c:
                     raise ValueError(f"{key} must have C elements")
                 d[key] = _chk(t, key)
+    if tile_counters is not None:
+        # zeroed int32 block: bands are handed out dynamically (robust when CUs are shared with a collective)
+        if tile_counters.dtype != torch.int32 or tile_counters.numel() < hip().BWD_TILE_COUNTERS:
+            raise ValueError("tile_counters must be BWD_TILE_COUNTERS int32")
+        d["tile_counters"] = _chk(tile_counters, "tile_counters", torch.int32)
     hip().conv_bwd_fused(d, stream())
     return out
 

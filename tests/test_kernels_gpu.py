@@ -199,7 +199,7 @@ def test_conv_pingpong_masked_dgrad(shape, with_extra):
     close(gt[c:], (want * xhat).reshape(-1, c).double().sum(0), 1e-4)
 
 
-@pytest.mark.parametrize("shape", [(5, 32, 16), (7, 16, 32), (9, 8, 64), (70, 8, 64)])
+@pytest.mark.parametrize("shape", [(5, 32, 16), (7, 16, 32), (9, 8, 64), (70, 8, 64), (300, 32, 16), (700, 16, 32)])
 @pytest.mark.parametrize("with_extra", [False, True])
 def test_conv_bwd_fused(shape, with_extra):
     # one kernel: masked data gradient + BatchNorm-backward sums + filter gradient (per-XCD copies)
@@ -217,8 +217,10 @@ def test_conv_bwd_fused(shape, with_extra):
     slots = torch.zeros(nv.STAT_SLOTS, n + 64, device=DEV)
     gs = nv.new_stats(c, DEV)
     assert nv.conv_bwd_fused_supported(x_pre)
+    # dynamic band scheduling on the larger case, static striding otherwise
+    ctr = torch.zeros(nv.hip().BWD_TILE_COUNTERS, device=DEV, dtype=torch.int32) if b > 32 else None
     got = nv.conv_bwd_fused(dy, x_pre, bn_state_for(x_pre, gamma, beta), nv.pack_weights(wt.detach(), flip=True),
-                            slots[0, :n].view(3, 3, c, c), gs, slot_stride=n + 64, extra=extra)
+                            slots[0, :n].view(3, 3, c, c), gs, slot_stride=n + 64, extra=extra, tile_counters=ctr)
     close(got, want)
     assert slots[:, n:].abs().max().item() == 0
     close(slots[:, :n].sum(0).view(dw_want.shape), dw_want)
