@@ -41,6 +41,95 @@ def cpu_floor(model: str):
     return None
 
 
+def bench_policy(args) -> None:
+    """Images/sec of the non-headline aggregation policies (same model, data, dtype and optimizer
+    as the headline; each step is forward + backward + the policy's aggregation + update)."""
+    from distributed_tensorflow_amd.parallel import control_plane
+    from distributed_tensorflow_amd.parallel.comm import Communicator
+    from distributed_tensorflow_amd.parallel.strategies import Backup, FullSync
+    from distributed_tensorflow_amd.train.replica import HipReplica
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X")
+    comm = Communicator.from_env(backend=args.backend)
+    world = comm.world
+    torch.manual_seed(1234 + comm.rank)
+    replica = HipReplica("resnet", args.batch, num_residual_blocks=MODELS[args.model], optimizer=args.optimizer,
+                         num_buckets=args.buckets if world > 1 else 1, weight_decay=2e-4)
+    with replica.stream_ctx():
+        comm.broadcast(replica.arena.params, 0)
+    board = None
+    if args.mode in ("backup", "async"):
+        name = control_plane.board_name_for("bench_" + args.mode, int(os.environ.get("MASTER_PORT", "0")))
+        if comm.is_chief:
+            board = control_plane.open_board(name, world, 0)
+        comm.barrier()
+        if not comm.is_chief:
+            board = control_plane.open_board(name, world, comm.rank)
+    detail = {}
+    if args.mode == "async":
+        from distributed_tensorflow_amd.parallel.async_ps import AsyncParameterShards
+
+        shards = AsyncParameterShards(replica, comm, board, args.staleness, name + "_ps", lambda version: args.lr)
+        step_fn = lambda i: shards.step()   # noqa: E731
+    else:
+        if args.mode == "backup":
+            m = args.aggregate if args.aggregate > 0 else max(1, world - 1)
+            strategy = Backup(comm, board, m)
+            detail["replicas_to_aggregate"] = strategy.m
+        else:
+            strategy = FullSync(comm, board, reduce_scatter=True)
+        step_fn = lambda i: strategy.step(replica, i, args.lr)   # noqa: E731
+    images = torch.randn(args.batch, 32, 32, 3, device=comm.device)
+    labels = torch.randint(0, 10, (args.batch,), device=comm.device)
+    replica.load_batch(images, labels)
+    for i in range(args.warmup):
+        r = step_fn(i)
+        if os.environ.get("DTF_BENCH_DEBUG"):
+            print("warmup", i, r, replica.loss_value(), file=sys.stderr, flush=True)
+    replica.synchronize()
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step_fn(args.warmup + i)
+    replica.synchronize()
+    torch.cuda.synchronize()
+    comm.barrier()
+    dt = time.perf_counter() - t0
+    final_loss = replica.loss_value()
+    if args.mode == "async":
+        shards.drain(30.0)
+        detail["async_stats"] = vars(shards.stats)
+        if os.environ.get("DTF_BENCH_DEBUG"):
+            print("after drain", final_loss, replica.loss_value(), file=sys.stderr, flush=True)
+    t = torch.tensor([dt], device=comm.device, dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if comm.is_chief:
+        value = args.batch * world * args.steps / dt
+        floor = cpu_floor(args.model)
+        print(json.dumps({
+            "metric": "images/sec (node) ResNet CIFAR-10 %s-SGD" % args.mode,
+            "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": round(value / floor, 2) if floor else None, "dtype": "fp32",
+            "data": "synthetic CIFAR-10-shaped images, random-init weights",
+            "config": dict(model=args.model, global_batch=args.batch * world, per_gpu_batch=args.batch, optimizer=args.optimizer,
+                           parallelism=f"dp{world}", mode=args.mode, final_loss=round(final_loss, 4), **detail),
+        }))
+    if board is not None:
+        comm.barrier()
+        if args.mode == "async":
+            shards.close()
+        if comm.is_chief:
+            type(board).unlink(name)
+    comm.close()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,7 +152,16 @@ def main() -> None:
                                                      "ranks share one GPU to rehearse the multi-rank path")
     ap.add_argument("--allreduce", choices=["rccl", "p2p"], default="rccl",
                     help="gradient all-reduce: RCCL, or the hand-written two-shot kernel over peer-mapped HBM")
+    ap.add_argument("--mode", choices=["sync", "sharded", "backup", "async"], default="sync",
+                    help="sync = the headline (all-reduce of every replica's gradient). The others time the framework's "
+                         "other aggregation policies through the same replica + strategy objects the training driver uses: "
+                         "sharded = reduce-scatter + per-shard optimizer + all-gather; backup = mean of the first "
+                         "--aggregate gradients (masked all-reduce); async = staleness-bounded parameter shards")
+    ap.add_argument("--aggregate", type=int, default=0, help="backup mode: gradients per update (default N-1)")
+    ap.add_argument("--staleness", type=int, default=4, help="async mode: staleness bound")
     args = ap.parse_args()
+    if args.mode != "sync":
+        return bench_policy(args)
 
     from distributed_tensorflow_amd.models.resnet_hip import ResNetHipStep
     from distributed_tensorflow_amd.ops import reference as ref
@@ -117,14 +215,21 @@ def main() -> None:
         stream.synchronize()
         comm.barrier()
         torch.cuda.synchronize()
+        # one event per step boundary (recorded on the step's stream, never waited on inside the
+        # timed region) gives the per-step GPU times for the p50
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        marks[0].record(stream)
+        for i in range(args.steps):
             one_step()
+            marks[i + 1].record(stream)
         stream.synchronize()
         torch.cuda.synchronize()
         comm.barrier()
         dt = time.perf_counter() - t0
         loss = step.loss_value()
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        p50 = per_step[len(per_step) // 2] if per_step else float("nan")
 
     t = torch.tensor([dt], device=comm.device, dtype=torch.float64)
     if world > 1:
@@ -144,6 +249,7 @@ def main() -> None:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms, 4),
+            "p50_ms_per_step": round(p50, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": round(value / floor, 2) if floor else None,

@@ -206,6 +206,9 @@ class HipReplica(ReplicaBase):
         return torch.cuda.stream(self.stream)
 
     def load_batch(self, images, labels) -> None:
+        if isinstance(images, torch.Tensor) and images.is_cuda:
+            # device tensors may still be being produced on the caller's stream
+            self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             x = torch.as_tensor(images, dtype=torch.float32)
             y = torch.as_tensor(labels)

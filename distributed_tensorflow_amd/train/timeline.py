@@ -6,7 +6,8 @@ DistributedLeNet/src/distributed_train.py:300-305,324-328). Here a step is a rec
 HIP kernels; the trace is built from HIP events recorded around each program segment (forward +
 backward pieces, the gradient collectives, the optimizer), written with the same file naming and
 the same chrome-trace JSON schema. Kernel-level detail comes from running the job under
-`rocprofv3 --kernel-trace`; roctx-style phase names are the span names used here.
+`rocprofv3 --kernel-trace`; every span is also emitted as a roctx range (torch.cuda.nvtx is roctx
+on ROCm), so `rocprofv3 --marker-trace` shows the same phase names next to the kernels.
 """
 from __future__ import annotations
 
@@ -17,6 +18,16 @@ from contextlib import contextmanager
 from typing import Dict, List, Optional
 
 import torch
+
+
+def _roctx(push: bool, name: str = "") -> None:
+    try:
+        if push:
+            torch.cuda.nvtx.range_push(name)
+        else:
+            torch.cuda.nvtx.range_pop()
+    except Exception:   # a torch build without the marker library: spans still work
+        pass
 
 
 class StepTimeline:
@@ -41,12 +52,16 @@ class StepTimeline:
             return
         h0 = time.perf_counter()
         ev = None
+        if self.use_cuda:
+            _roctx(True, name)
         if self.use_cuda and stream is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(stream)
         try:
             yield
         finally:
+            if self.use_cuda:
+                _roctx(False)
             if ev is not None:
                 ev[1].record(stream)
                 self._gpu_spans.append((name, ev[0], ev[1]))
