@@ -98,6 +98,18 @@ PYBIND11_MODULE(_hip, m) {
     return conv_bwd_fused(a, as_stream(stream));
   });
   m.def("conv_bwd_fused_supported", &conv_bwd_fused_supported);
+  m.def("conv5x5_tile", [](const py::dict& d, uint64_t stream) {
+    Conv5x5Args a{};
+    P(x, const float); P(w, const float); P(bias, const float); P(y, float);
+    V(B); V(Cin); V(Cout); V(flip); V(imgs);
+    conv5x5_tile(a, as_stream(stream));
+  });
+  m.def("conv5x5_pack", [](const py::dict& d, uint64_t stream) {
+    Conv5x5PackArgs a{};
+    P(w, const float); P(out, float); V(Cin); V(Cout);
+    conv5x5_pack(a, as_stream(stream));
+  });
+  m.def("conv5x5_tile_supported", &conv5x5_tile_supported);
   m.attr("BWD_TILE_COUNTERS") = (int)kBwdTileCounters;
   m.def("pack_multi", [](uint64_t params, uint64_t packed, uint64_t table, int n_entries, int total_blocks,
                          uint64_t stream) {

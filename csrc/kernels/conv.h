@@ -133,4 +133,27 @@ constexpr int kBwdTileCounters = 32;   // 8 XCDs x up to 4 channel splits
 bool conv_bwd_fused_supported(int B, int H, int W, int C);
 size_t conv_bwd_fused(const ConvBwdFusedArgs& a, hipStream_t stream);
 
+// ---- 5x5 stride-1 SAME convolution over 14x14 maps, whole images per workgroup (conv5x5_tile.hip)
+// Forward form (flip = 0): Cin 32 -> Cout 64, y = relu(conv(x, w) + bias), w = conv5x5_pack of
+// the HWIO filter ([25][Cout][Cin]). Data-gradient form (flip = 1): Cin 64 -> Cout 32 over the
+// output gradient, w = the HWIO filter itself (its [tap][in][out] rows are the [tap][Cout][Cin]
+// rows of the transposed problem; the kernel walks the taps backwards), no bias / activation.
+struct Conv5x5Args {
+  const float* x;     // [B,14,14,Cin]
+  const float* w;     // [25][Cout][Cin]
+  const float* bias;  // [Cout], forward form only
+  float* y;           // [B,14,14,Cout]
+  int B, Cin, Cout;
+  int flip;
+  int imgs;           // images per workgroup tile: 0 = choose by batch, 1 or 2 (forward form)
+};
+struct Conv5x5PackArgs {
+  const float* w;   // [25][Cin][Cout]
+  float* out;       // [25][Cout][Cin]
+  int Cin, Cout;
+};
+bool conv5x5_tile_supported(int H, int W, int Cin, int Cout);
+void conv5x5_tile(const Conv5x5Args& a, hipStream_t stream);
+void conv5x5_pack(const Conv5x5PackArgs& a, hipStream_t stream);
+
 }  // namespace dtf

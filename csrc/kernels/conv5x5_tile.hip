@@ -1,0 +1,227 @@
+// 5x5, stride 1, SAME convolution over 14x14 feature maps: the second convolution of the MNIST
+// LeNet (32 -> 64 channels, reference: DistributedLeNet/src/mnist.py:119-123) and, with the taps
+// flipped and the channel roles swapped, its data gradient (64 -> 32).
+//
+// The general implicit-GEMM kernel stages both operands through LDS in k-chunks with a barrier per
+// chunk and reached ~30 % of the fp32 MFMA rate on this shape. Here:
+//   * a workgroup's tile is IMGS whole images (196 pixels each): the zero-padded 18x18 input planes
+//     sit in LDS for all 25 taps, so every input element is read from HBM exactly once and the tap
+//     loop has no barrier;
+//   * the 5*5*Cin*Cout filter (205 KB) does not fit in LDS next to them and does not need to: one
+//     tap's 16 x Cin slice per wave is a few 16-byte loads per lane straight from L2 into the MFMA
+//     A registers, fetched one tap ahead (a tap is >= 3500 MFMA cycles per wave);
+//   * M = output channels, N = pixels, so a lane ends up with 4 consecutive output channels of one
+//     pixel (one 16-byte store); k is permuted so one ds_read_b128 feeds four MFMAs;
+//   * the next tile's input is prefetched into registers while the current one is multiplied.
+// 196 is not a multiple of 16: pixel tiles run over the linearised pixels of the IMGS images
+// (2 images = 24.5 tiles, 2 % padding) with per-lane window offsets computed once.
+#include "common.h"
+#include "conv.h"
+
+namespace dtf {
+namespace {
+
+constexpr int kHW = 14;            // feature-map height and width
+constexpr int kPW = kHW + 4;       // padded plane (halo 2 on every side)
+constexpr int kImgPx = kHW * kHW;  // 196
+
+template <int CIN, int COUT, int IMGS>
+struct C5 {
+  static constexpr int PS = CIN + 4;                 // LDS pixel stride (floats)
+  static constexpr int PX = IMGS * kImgPx;           // pixels per tile
+  static constexpr int NT = (PX + 15) / 16;          // 16-pixel MFMA tiles per workgroup tile
+  static constexpr int MT = COUT / 16;               // 16-channel output tiles
+  static constexpr int WPM = 4 / MT;                 // waves sharing one output-channel tile
+  static constexpr int NTW = (NT + WPM - 1) / WPM;   // pixel tiles per wave
+  static constexpr int KG = CIN / 16;                // 16-channel groups per tap
+  static constexpr int C4 = CIN / 4;
+  static constexpr int CHUNKS = PX * C4;             // 16-byte chunks of a tile's input
+  static constexpr int NPF = (CHUNKS + 255) / 256;
+  static constexpr int LDS_FLOATS = IMGS * kPW * kPW * PS;
+  static_assert(COUT == 32 || COUT == 64, "4 waves cover 2 or 4 output-channel tiles");
+  static_assert(CIN % 16 == 0, "input channels come in groups of 16");
+};
+
+// x [B,14,14,CIN]; w [25][COUT][CIN] (FLIP: tap t reads w[24-t]); y [B,14,14,COUT].
+template <int CIN, int COUT, int IMGS, bool FLIP, bool BIAS_RELU>
+__global__ __launch_bounds__(256) void conv5x5_tile_kernel(Conv5x5Args a) {
+  using G = C5<CIN, COUT, IMGS>;
+  extern __shared__ __align__(16) float lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, n = lane & 15;
+  const int mtile = wave % G::MT, nsub = wave / G::MT;
+  const int co0 = mtile * 16;
+  const int n_tiles = (a.B + IMGS - 1) / IMGS;
+
+  // zero the planes once: the halo is never written again
+  for (int i = tid; i < G::LDS_FLOATS / 4; i += 256) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // window origin (top-left of the 5x5 footprint in the padded plane) of this lane's pixel in each
+  // of the wave's pixel tiles, plus the lane's channel offset inside a 16-channel group
+  int boff[G::NTW];
+#pragma unroll
+  for (int i = 0; i < G::NTW; ++i) {
+    int q = (nsub * G::NTW + i) * 16 + n;
+    if (q > G::PX - 1) q = G::PX - 1;
+    const int img = q / kImgPx, r = q % kImgPx;
+    boff[i] = ((img * kPW + r / kHW) * kPW + r % kHW) * G::PS + 4 * g;
+  }
+  // staging: chunk c of the tile's input is contiguous in global memory; its LDS home is fixed
+  int sdst[G::NPF];
+#pragma unroll
+  for (int k = 0; k < G::NPF; ++k) {
+    const int c = tid + 256 * k;
+    const int px = (c < G::CHUNKS ? c : 0) / G::C4, c4 = c % G::C4;
+    const int img = px / kImgPx, r = px % kImgPx;
+    sdst[k] = ((img * kPW + r / kHW + 2) * kPW + r % kHW + 2) * G::PS + 4 * c4;
+  }
+  float4 pf[G::NPF];
+  auto fetch = [&](int tile) {
+    const int valid = min(G::PX, (a.B - tile * IMGS) * kImgPx) * G::C4;
+    const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)tile * G::PX * CIN);
+#pragma unroll
+    for (int k = 0; k < G::NPF; ++k) {
+      const int c = tid + 256 * k;
+      pf[k] = c < valid ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (BIAS_RELU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias4[i] = a.bias[co0 + 4 * g + i];
+  }
+  // this lane's filter row: output channel co0 + n, input channels 16 j + 4 g + (0..3)
+  const float* wrow = a.w + (size_t)(co0 + n) * CIN + 4 * g;
+  constexpr int W_TAP = COUT * CIN;
+
+  int tile = blockIdx.x;
+  if (tile < n_tiles) fetch(tile);
+  for (; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();   // every wave is done reading the previous tile (and the zero fill landed)
+#pragma unroll
+    for (int k = 0; k < G::NPF; ++k)
+      if (tid + 256 * k < G::CHUNKS) *reinterpret_cast<float4*>(lds + sdst[k]) = pf[k];
+    __syncthreads();
+    if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
+
+    floatx4 acc[G::NTW];
+#pragma unroll
+    for (int i = 0; i < G::NTW; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    float4 wcur[G::KG], wnxt[G::KG];
+    {
+      const float* w0 = wrow + (size_t)(FLIP ? 24 : 0) * W_TAP;
+#pragma unroll
+      for (int j = 0; j < G::KG; ++j) wcur[j] = *reinterpret_cast<const float4*>(w0 + 16 * j);
+    }
+    int toff = 0;   // LDS offset of the tap inside the window
+#pragma unroll 1
+    for (int kh = 0; kh < 5; ++kh) {
+#pragma unroll 1
+      for (int kw = 0; kw < 5; ++kw) {
+        const int tap = kh * 5 + kw;
+        if (tap < 24) {
+          const float* wn = wrow + (size_t)(FLIP ? 23 - tap : tap + 1) * W_TAP;
+#pragma unroll
+          for (int j = 0; j < G::KG; ++j) wnxt[j] = *reinterpret_cast<const float4*>(wn + 16 * j);
+        }
+        const float* base = lds + toff;
+#pragma unroll
+        for (int j = 0; j < G::KG; ++j) {
+#pragma unroll
+          for (int i = 0; i < G::NTW; ++i) {
+            // a wave whose last pixel tile lies beyond the image multiplies a clamped copy of the
+            // last pixel instead of branching (the result is not stored)
+            const float4 b = *reinterpret_cast<const float4*>(base + boff[i] + 16 * j);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[j].x, b.x, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[j].y, b.y, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[j].z, b.z, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[j].w, b.w, acc[i], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < G::KG; ++j) wcur[j] = wnxt[j];
+        toff += G::PS;
+      }
+      toff += (kPW - 5) * G::PS;
+    }
+
+    // lane holds output channels co0 + 4g .. +3 of pixel 16 t + n
+    const int valid_px = min(G::PX, (a.B - tile * IMGS) * kImgPx);
+    float* yt = a.y + (size_t)tile * G::PX * COUT + co0 + 4 * g;
+#pragma unroll
+    for (int i = 0; i < G::NTW; ++i) {
+      const int q = (nsub * G::NTW + i) * 16 + n;
+      if (q < valid_px) {
+        float4 o;
+        o.x = acc[i][0] + bias4[0];
+        o.y = acc[i][1] + bias4[1];
+        o.z = acc[i][2] + bias4[2];
+        o.w = acc[i][3] + bias4[3];
+        if constexpr (BIAS_RELU) {
+          o.x = fmaxf(o.x, 0.f);
+          o.y = fmaxf(o.y, 0.f);
+          o.z = fmaxf(o.z, 0.f);
+          o.w = fmaxf(o.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(yt + (size_t)q * COUT) = o;
+      }
+    }
+  }
+}
+
+// [25][CIN][COUT] (HWIO filter) -> [25][COUT][CIN]
+__global__ __launch_bounds__(256) void conv5x5_pack_kernel(Conv5x5PackArgs a) {
+  const int per_tap = a.Cin * a.Cout;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 25 * per_tap) return;
+  const int tap = i / per_tap, r = i % per_tap;
+  const int co = r / a.Cin, ci = r % a.Cin;
+  a.out[i] = a.w[(size_t)tap * per_tap + ci * a.Cout + co];
+}
+
+template <int CIN, int COUT, int IMGS, bool FLIP, bool BIAS_RELU>
+void launch_c5(const Conv5x5Args& a, hipStream_t stream) {
+  using G = C5<CIN, COUT, IMGS>;
+  auto kernel = conv5x5_tile_kernel<CIN, COUT, IMGS, FLIP, BIAS_RELU>;
+  const size_t shmem = (size_t)G::LDS_FLOATS * sizeof(float);
+  static const int bpc = [&] {
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), shmem);
+    int nb = 0;
+    DTF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, shmem));
+    return nb < 1 ? 1 : nb;
+  }();
+  const int n_tiles = (a.B + IMGS - 1) / IMGS;
+  const int cap = 256 * bpc;
+  const int iters = ceil_div(n_tiles, cap);
+  const int grid = ceil_div(n_tiles, iters);
+  launch("conv5x5_tile", kernel, dim3(grid), dim3(256), shmem, stream, a);
+}
+
+}  // namespace
+
+bool conv5x5_tile_supported(int H, int W, int Cin, int Cout) {
+  return H == kHW && W == kHW && ((Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 32));
+}
+
+void conv5x5_tile(const Conv5x5Args& a, hipStream_t stream) {
+  if (a.B < 1) throw std::runtime_error("conv5x5_tile: empty batch");
+  if (a.Cin == 32 && a.Cout == 64 && !a.flip) {
+    if (!a.bias) throw std::runtime_error("conv5x5_tile: the 32->64 forward form needs a bias");
+    // two images per tile halve the padding of the last pixel tile; one image per tile keeps
+    // every CU busy at small batches
+    if (a.imgs == 2 || (a.imgs == 0 && a.B >= 1024)) return launch_c5<32, 64, 2, false, true>(a, stream);
+    return launch_c5<32, 64, 1, false, true>(a, stream);
+  }
+  if (a.Cin == 64 && a.Cout == 32 && a.flip) return launch_c5<64, 32, 1, true, false>(a, stream);
+  throw std::runtime_error("conv5x5_tile: unsupported channel counts / direction");
+}
+
+void conv5x5_pack(const Conv5x5PackArgs& a, hipStream_t stream) {
+  const int total = 25 * a.Cin * a.Cout;
+  launch("conv5x5_pack", conv5x5_pack_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, a);
+}
+
+}  // namespace dtf

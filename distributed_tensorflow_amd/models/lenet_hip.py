@@ -1,6 +1,7 @@
 """MI355X training/eval step of the MNIST LeNet, recorded as a step program.
 
-forward   conv1/conv2 = implicit-GEMM MFMA kernels with fused bias + ReLU, 2x2 SAME max pools that
+forward   conv1 = implicit-GEMM MFMA kernel, conv2 = whole-image 5x5 MFMA kernel (input planes resident
+          in LDS, filter streamed from L2), both with fused bias + ReLU, 2x2 SAME max pools that
           keep a 2-bit argmax, FC1 = split-K MFMA GEMM with bias + ReLU, Philox dropout whose mask
           is regenerated (not stored) in backward, FC2 GEMM with bias, fused softmax
           cross-entropy that also emits d(loss)/d(logits).
@@ -40,8 +41,7 @@ class LeNetHipStep(StepProgramBase):
         self._init_common((28, 28, 1))
         a = arena
         self.wpk1 = torch.empty(nv.packed_floats(5, 1, 32, False), **f32)
-        self.wpk2 = torch.empty(nv.packed_floats(5, 32, 64, False), **f32)
-        self.wpk2_t = torch.empty(nv.packed_floats(5, 32, 64, True), **f32)
+        self.wpk2 = torch.empty(25 * 32 * 64, **f32)   # [tap][out][in], the whole-image kernel's operand
         self.a1 = torch.empty((B, 28, 28, 32), **f32)
         self.a2 = torch.empty((B, 14, 14, 64), **f32)
         self.h = torch.empty((B, 512), **f32)
@@ -64,11 +64,11 @@ class LeNetHipStep(StepProgramBase):
         try:
             self._record_prologue()
             nv.pack_weights(a.param("conv1_weights"), False, self.wpk1)
-            nv.pack_weights(a.param("conv2_weights"), False, self.wpk2)
+            nv.conv5x5_pack(a.param("conv2_weights"), self.wpk2)
             # ---------------- forward
             nv.conv_fprop(self.images, self.wpk1, ks=5, cout=32, epi_mode=nv.EPI_BIAS_RELU, bias=a.param("conv1_biases"), out=self.a1)
             self.p1, self.arg1 = nv.maxpool2x2_fwd(self.a1)
-            nv.conv_fprop(self.p1, self.wpk2, ks=5, cout=64, epi_mode=nv.EPI_BIAS_RELU, bias=a.param("conv2_biases"), out=self.a2)
+            nv.conv5x5_tile(self.p1, self.wpk2, bias=a.param("conv2_biases"), out=self.a2)
             self.p2, self.arg2 = nv.maxpool2x2_fwd(self.a2)
             flat = self.p2.view(B, -1)
             nv.gemm(flat, a.param("fc1_weights"), bias=a.param("fc1_biases"), relu=True, out=self.h)
@@ -81,7 +81,6 @@ class LeNetHipStep(StepProgramBase):
             nv.softmax_xent(self.logits, self.labels, self.loss, self.dlogits if self.training else None, self.correct)
             if self.training:
                 # ---------------- backward
-                nv.pack_weights(a.param("conv2_weights"), True, self.wpk2_t)
                 nv.gemm(hd, self.dlogits, trans_a=True, out=a.grad("fc2_weights"))
                 nv.col_sum(self.dlogits, a.grad("fc2_biases"))
                 nv.gemm(self.dlogits, a.param("fc2_weights"), trans_b=True, out=self.dh)
@@ -111,7 +110,8 @@ class LeNetHipStep(StepProgramBase):
 
                 nv.conv_wgrad(self.p1, da2, slot_view("conv2_weights"), stride=1, slot_stride=conv_end)
                 nv.col_sum(da2.view(-1, 64), a.grad("conv2_biases"))
-                nv.conv_fprop(da2, self.wpk2_t, ks=5, cout=32, pad=2, out_hw=(14, 14), out=self.dp1)
+                # data gradient: the same kernel over the unpacked filter, taps walked backwards
+                nv.conv5x5_tile(da2, a.param("conv2_weights"), flip=True, out=self.dp1)
                 da1 = nv.maxpool2x2_bwd(self.dp1, self.arg1, self.p1, (B, 28, 28, 32), relu_mask=True)
                 self.da1 = da1
                 nv.conv_wgrad(self.images, da1, slot_view("conv1_weights"), stride=1, slot_stride=conv_end)

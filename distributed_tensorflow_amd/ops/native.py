@@ -286,6 +286,52 @@ def conv_wgrad(
     return dw
 
 
+def conv5x5_tile_supported(h: int, w_: int, cin: int, cout: int) -> bool:
+    return bool(hip().conv5x5_tile_supported(h, w_, cin, cout))
+
+
+def conv5x5_pack(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """HWIO 5x5 filter [5,5,Cin,Cout] -> [25][Cout][Cin], the forward operand of conv5x5_tile."""
+    require()
+    if w.dim() != 4 or w.shape[0] != 5 or w.shape[1] != 5:
+        raise ValueError("conv5x5_pack: expected a [5,5,Cin,Cout] filter")
+    cin, cout = int(w.shape[2]), int(w.shape[3])
+    if out is None:
+        out = torch.empty(25 * cin * cout, device=w.device, dtype=torch.float32)
+    elif out.numel() != 25 * cin * cout:
+        raise ValueError("conv5x5_pack: out has the wrong size")
+    hip().conv5x5_pack(dict(w=_chk(w, "w"), out=_chk(out, "out"), Cin=cin, Cout=cout), stream())
+    return out
+
+
+def conv5x5_tile(x: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = None, flip: bool = False,
+                 out: Optional[torch.Tensor] = None, imgs: int = 0) -> torch.Tensor:
+    """5x5 stride-1 SAME convolution over [B,14,14,C] maps with whole images per workgroup.
+    flip=False: x has 32 channels, w = conv5x5_pack(filter), returns relu(conv + bias) with 64
+    channels. flip=True: x is the 64-channel output gradient, w = the [5,5,32,64] filter itself,
+    returns the 32-channel input gradient (see csrc/kernels/conv.h: Conv5x5Args)."""
+    require()
+    if x.dim() != 4 or x.shape[1] != 14 or x.shape[2] != 14:
+        raise ValueError("conv5x5_tile: expected [B,14,14,C] input")
+    b, cin = int(x.shape[0]), int(x.shape[3])
+    cout = 32 if flip else 64
+    if cin != (64 if flip else 32) or w.numel() != 25 * 32 * 64:
+        raise ValueError("conv5x5_tile: channel counts must be 32->64 (forward) or 64->32 (flip)")
+    if imgs not in (0, 1, 2):
+        raise ValueError("conv5x5_tile: imgs must be 0, 1 or 2")
+    if out is None:
+        out = torch.empty((b, 14, 14, cout), device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != (b, 14, 14, cout):
+        raise ValueError("conv5x5_tile: out has the wrong shape")
+    d = dict(x=_chk(x, "x"), w=_chk(w, "w"), y=_chk(out, "y"), B=b, Cin=cin, Cout=cout, flip=int(flip), imgs=imgs)
+    if not flip:
+        if bias is None or bias.numel() != cout:
+            raise ValueError("conv5x5_tile: the forward form needs a bias of Cout elements")
+        d["bias"] = _chk(bias, "bias")
+    hip().conv5x5_tile(d, stream())
+    return out
+
+
 def conv_bwd_fused_supported(x: torch.Tensor) -> bool:
     b, h, w_, c = x.shape
     return bool(hip().conv_bwd_fused_supported(b, h, w_, c))

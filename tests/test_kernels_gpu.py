@@ -104,6 +104,29 @@ def test_conv_fprop_bias_relu():
     close(nv.conv_fprop(x, nv.pack_weights(wt), ks=5, cout=64, epi_mode=nv.EPI_BIAS_RELU, bias=bias), want)
 
 
+@pytest.mark.parametrize("b,imgs", [(1, 1), (3, 1), (3, 2), (4, 2), (37, 0), (1030, 0)])
+def test_conv5x5_tile_forward(b, imgs):
+    """Whole-image 5x5 kernel (LeNet conv2 shape): bias + ReLU epilogue, odd batches so the last
+    tile is partly empty, both images-per-tile variants."""
+    assert nv.conv5x5_tile_supported(14, 14, 32, 64)
+    x = rnd(b, 14, 14, 32)
+    wt = rnd(5, 5, 32, 64, scale=0.05)
+    bias = rnd(64, scale=0.3)
+    want = torch.relu(ref.conv2d_same(x, wt, 1) + bias)
+    got = nv.conv5x5_tile(x, nv.conv5x5_pack(wt), bias=bias, imgs=imgs)
+    close(got, want)
+
+
+@pytest.mark.parametrize("b", [1, 5, 300])
+def test_conv5x5_tile_data_gradient(b):
+    dy = rnd(b, 14, 14, 64)
+    wt = rnd(5, 5, 32, 64, scale=0.05)
+    x = rnd(b, 14, 14, 32).requires_grad_(True)
+    ref.conv2d_same(x, wt, 1).backward(dy)
+    got = nv.conv5x5_tile(dy, wt, flip=True)
+    close(got, x.grad)
+
+
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[3] >= 16])
 def test_conv_dgrad(case):
     b, h, w, cin, cout, ks, s = case
