@@ -110,6 +110,17 @@ PYBIND11_MODULE(_hip, m) {
     conv5x5_pack(a, as_stream(stream));
   });
   m.def("conv5x5_tile_supported", &conv5x5_tile_supported);
+  m.def("conv1_pool_fwd", [](const py::dict& d, uint64_t stream) {
+    Conv1PoolFwdArgs a{};
+    P(x, const float); P(w, const float); P(bias, const float); P(p, float); P(arg, unsigned char); V(B);
+    conv1_pool_fwd(a, as_stream(stream));
+  });
+  m.def("conv1_pool_bwd", [](const py::dict& d, uint64_t stream) {
+    Conv1PoolBwdArgs a{};
+    P(x, const float); P(dp, const float); P(arg, const unsigned char); P(p, const float); P(dw, float); P(dbias, float);
+    V(slot_stride); V(B);
+    conv1_pool_bwd(a, as_stream(stream));
+  });
   m.attr("BWD_TILE_COUNTERS") = (int)kBwdTileCounters;
   m.def("pack_multi", [](uint64_t params, uint64_t packed, uint64_t table, int n_entries, int total_blocks,
                          uint64_t stream) {

@@ -146,6 +146,17 @@ void maxpool2x2_fwd(const MaxPoolArgs& a, hipStream_t stream);
 struct MaxPoolBwdArgs { const float* dy; const unsigned char* argmax; const float* y; float* dx; int B, H, W, C; int relu_mask; };
 void maxpool2x2_bwd(const MaxPoolBwdArgs& a, hipStream_t stream);
 
+// First LeNet layer fused with its 2x2/2 max pool (lenet_conv1.hip): 28x28x1 images, 5x5x1x32 HWIO
+// filter, SAME padding. Forward writes only the pooled ReLU maximum p [B,14,14,32] and the winner
+// position arg (same encoding as maxpool2x2_fwd). Backward adds the filter gradient [25][32] and
+// the bias gradient [32] computed from the pooled gradient dp; with slot_stride != 0 they go to
+// the copy of the block's XCD (dw + slot * slot_stride, dbias + slot * slot_stride).
+struct Conv1PoolFwdArgs { const float* x; const float* w; const float* bias; float* p; unsigned char* arg; int B; };
+void conv1_pool_fwd(const Conv1PoolFwdArgs& a, hipStream_t stream);
+struct Conv1PoolBwdArgs { const float* x; const float* dp; const unsigned char* arg; const float* p; float* dw; float* dbias;
+                          int slot_stride; int B; };
+void conv1_pool_bwd(const Conv1PoolBwdArgs& a, hipStream_t stream);
+
 // dropout with a counter-based Philox-4x32-10 stream: mask regenerated from (seed, offset)
 // in backward (reference: DistributedLeNet/src/mnist.py:139-140, keep_prob 0.5, seed 66478)
 struct DropoutArgs { const float* x; float* y; long long n; float keep_prob; unsigned long long seed; unsigned long long offset;

@@ -1,7 +1,8 @@
 """MI355X training/eval step of the MNIST LeNet, recorded as a step program.
 
-forward   conv1 = implicit-GEMM MFMA kernel, conv2 = whole-image 5x5 MFMA kernel (input planes resident
-          in LDS, filter streamed from L2), both with fused bias + ReLU, 2x2 SAME max pools that
+forward   conv1 + bias + ReLU + pool = one kernel (its 28x28x32 activation never reaches memory),
+          conv2 = whole-image 5x5 MFMA kernel (input planes resident in LDS, filter streamed from
+          L2) with fused bias + ReLU, 2x2 SAME max pools that
           keep a 2-bit argmax, FC1 = split-K MFMA GEMM with bias + ReLU, Philox dropout whose mask
           is regenerated (not stored) in backward, FC2 GEMM with bias, fused softmax
           cross-entropy that also emits d(loss)/d(logits).
@@ -40,9 +41,9 @@ class LeNetHipStep(StepProgramBase):
         f32 = dict(device=dev, dtype=torch.float32)
         self._init_common((28, 28, 1))
         a = arena
-        self.wpk1 = torch.empty(nv.packed_floats(5, 1, 32, False), **f32)
         self.wpk2 = torch.empty(25 * 32 * 64, **f32)   # [tap][out][in], the whole-image kernel's operand
-        self.a1 = torch.empty((B, 28, 28, 32), **f32)
+        self.p1 = torch.empty((B, 14, 14, 32), **f32)
+        self.arg1 = torch.empty((B, 14, 14, 32), device=dev, dtype=torch.uint8)
         self.a2 = torch.empty((B, 14, 14, 64), **f32)
         self.h = torch.empty((B, 512), **f32)
         self.hd = torch.empty((B, 512), **f32)
@@ -63,11 +64,10 @@ class LeNetHipStep(StepProgramBase):
         p.begin_record()
         try:
             self._record_prologue()
-            nv.pack_weights(a.param("conv1_weights"), False, self.wpk1)
             nv.conv5x5_pack(a.param("conv2_weights"), self.wpk2)
             # ---------------- forward
-            nv.conv_fprop(self.images, self.wpk1, ks=5, cout=32, epi_mode=nv.EPI_BIAS_RELU, bias=a.param("conv1_biases"), out=self.a1)
-            self.p1, self.arg1 = nv.maxpool2x2_fwd(self.a1)
+            # conv1 + bias + ReLU + pool in one kernel: the 28x28x32 activation is never written
+            nv.conv1_pool_fwd(self.images, a.param("conv1_weights"), a.param("conv1_biases"), out=self.p1, arg=self.arg1)
             nv.conv5x5_tile(self.p1, self.wpk2, bias=a.param("conv2_biases"), out=self.a2)
             self.p2, self.arg2 = nv.maxpool2x2_fwd(self.a2)
             flat = self.p2.view(B, -1)
@@ -112,10 +112,9 @@ class LeNetHipStep(StepProgramBase):
                 nv.col_sum(da2.view(-1, 64), a.grad("conv2_biases"))
                 # data gradient: the same kernel over the unpacked filter, taps walked backwards
                 nv.conv5x5_tile(da2, a.param("conv2_weights"), flip=True, out=self.dp1)
-                da1 = nv.maxpool2x2_bwd(self.dp1, self.arg1, self.p1, (B, 28, 28, 32), relu_mask=True)
-                self.da1 = da1
-                nv.conv_wgrad(self.images, da1, slot_view("conv1_weights"), stride=1, slot_stride=conv_end)
-                nv.col_sum(da1.view(-1, 32), a.grad("conv1_biases"))
+                # pool backward + ReLU mask + filter and bias gradients of conv1 in one kernel
+                nv.conv1_pool_bwd(self.images, self.dp1, self.arg1, self.p1, slot_view("conv1_weights"),
+                                  slot_view("conv1_biases"), slot_stride=conv_end)
                 nv.slot_reduce(a.grads, self._wslots, 0, conv_end)
                 self.bucket_ranges.append((0, lo))
                 p.mark_segment()

@@ -612,6 +612,45 @@ def maxpool2x2_fwd(x):
     return y, arg
 
 
+def conv1_pool_fwd(x, w, bias, out=None, arg=None):
+    """relu(conv5x5 SAME(x, w) + bias) followed by the 2x2/2 max pool, for [B,28,28,1] images and a
+    [5,5,1,32] filter, without materialising the full-resolution activation. Returns the pooled
+    maximum [B,14,14,32] and the winner positions (uint8, as maxpool2x2_fwd)."""
+    require()
+    b = int(x.shape[0])
+    if tuple(x.shape[1:]) != (28, 28, 1) or tuple(w.shape) != (5, 5, 1, 32) or bias.numel() != 32:
+        raise ValueError("conv1_pool_fwd: expected [B,28,28,1] images, a [5,5,1,32] filter and 32 biases")
+    if out is None:
+        out = torch.empty((b, 14, 14, 32), device=x.device, dtype=torch.float32)
+    if arg is None:
+        arg = torch.empty((b, 14, 14, 32), device=x.device, dtype=torch.uint8)
+    if tuple(out.shape) != (b, 14, 14, 32) or tuple(arg.shape) != (b, 14, 14, 32) or arg.dtype != torch.uint8:
+        raise ValueError("conv1_pool_fwd: outputs must be [B,14,14,32] (float32 / uint8)")
+    hip().conv1_pool_fwd(dict(x=_chk(x, "x"), w=_chk(w, "w"), bias=_chk(bias, "bias"), p=_chk(out, "p"),
+                              arg=_chk(arg, "arg", torch.uint8), B=b), stream())
+    return out, arg
+
+
+def conv1_pool_bwd(x, dp, arg, p, dw, dbias, slot_stride: int = 0):
+    """Adds the filter gradient (dw [5,5,1,32]) and bias gradient (dbias [32]) of conv1_pool_fwd
+    given the gradient dp at the pooled output; with slot_stride the sums go to the per-XCD
+    copies starting at dw / dbias (see slot_reduce)."""
+    require()
+    b = int(x.shape[0])
+    shp = (b, 14, 14, 32)
+    if tuple(x.shape[1:]) != (28, 28, 1) or tuple(dp.shape) != shp or tuple(arg.shape) != shp or tuple(p.shape) != shp:
+        raise ValueError("conv1_pool_bwd: shape mismatch")
+    if dw.numel() != 25 * 32 or dbias.numel() != 32:
+        raise ValueError("conv1_pool_bwd: dw must hold 5*5*1*32 and dbias 32 elements")
+    if slot_stride:
+        for t in (dw, dbias):
+            last = (t.storage_offset() + (STAT_SLOTS - 1) * slot_stride + t.numel()) * 4
+            if last > t.untyped_storage().nbytes():
+                raise ValueError("conv1_pool_bwd: the slot copies do not fit the gradient storage")
+    hip().conv1_pool_bwd(dict(x=_chk(x, "x"), dp=_chk(dp, "dp"), arg=_chk(arg, "arg", torch.uint8), p=_chk(p, "p"),
+                              dw=_chk(dw, "dw"), dbias=_chk(dbias, "dbias"), slot_stride=slot_stride, B=b), stream())
+
+
 def maxpool2x2_bwd(dy, arg, y, x_shape, relu_mask: bool = False):
     require()
     b, h, w_, c = x_shape

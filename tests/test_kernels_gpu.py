@@ -511,6 +511,39 @@ def test_flat_ops_and_elementwise():
     assert abs(nv.zero_fraction(torch.relu(a)) - float((torch.relu(a) == 0).float().mean())) < 1e-6
 
 
+@pytest.mark.parametrize("b", [1, 3, 70])
+def test_conv1_pool_fused_forward_and_backward(b):
+    """Fused first LeNet layer: pooled maximum / winner against conv + bias + ReLU + max-pool, and
+    filter / bias gradients against autograd of the unfused chain."""
+    x = rnd(b, 28, 28, 1)
+    wt = rnd(5, 5, 1, 32, scale=0.3)
+    bias = rnd(32, scale=0.2)
+    xr = x.clone().requires_grad_(False)
+    wr, br = wt.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    act = torch.relu(ref.conv2d_same(xr, wr, 1) + br)
+    pooled = torch.nn.functional.max_pool2d(act.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    p, arg = nv.conv1_pool_fwd(x, wt, bias)
+    close(p, pooled)
+    # winner positions agree with the unfused kernels wherever the maximum is positive
+    _, arg_ref = nv.maxpool2x2_fwd(act.detach().contiguous())
+    pos = pooled > 1e-6
+    assert torch.equal(arg[pos], arg_ref[pos])
+    dp = rnd(b, 14, 14, 32)
+    pooled.backward(dp)
+    slots = torch.zeros(nv.STAT_SLOTS, 1024, device=DEV)
+    dw = slots[0, :800].view(5, 5, 1, 32)
+    db = slots[0, 800:832]
+    nv.conv1_pool_bwd(x, dp, arg, p, dw, db, slot_stride=1024)
+    total = slots.sum(0)
+    close(total[:800].view(5, 5, 1, 32), wr.grad, tol=5e-4)
+    close(total[800:832], br.grad, tol=5e-4)
+    # without slots the sums land in place
+    dw2, db2 = torch.zeros(5, 5, 1, 32, device=DEV), torch.zeros(32, device=DEV)
+    nv.conv1_pool_bwd(x, dp, arg, p, dw2, db2)
+    close(dw2, wr.grad, tol=5e-4)
+    close(db2, br.grad, tol=5e-4)
+
+
 def test_maxpool_same():
     for shape in [(3, 28, 28, 32), (3, 14, 14, 64), (2, 7, 7, 8)]:
         x = rnd(*shape)
