@@ -568,7 +568,7 @@ def test_dropout_statistics_and_replay():
     assert not torch.equal(y, nv.dropout(x, 0.5, 66478, n // 4))
 
 
-@pytest.mark.parametrize("shape", [(256, 3136, 512), (100, 512, 10), (37, 70, 129)])
+@pytest.mark.parametrize("shape", [(256, 3136, 512), (100, 512, 10), (37, 70, 129), (1024, 512, 3136), (132, 260, 388), (520, 1028, 772)])
 def test_gemm_variants(shape):
     m, k, n = shape
     a, b = rnd(m, k), rnd(k, n, seed=3)
@@ -577,6 +577,10 @@ def test_gemm_variants(shape):
     close(nv.gemm(a, b, bias=bias, relu=True), torch.relu(a @ b + bias))
     close(nv.gemm(a.t().contiguous(), b, trans_a=True), a @ b)
     close(nv.gemm(a, b.t().contiguous(), trans_b=True), a @ b)
+    close(nv.gemm(a.t().contiguous(), b.t().contiguous(), trans_a=True, trans_b=True), a @ b)
+    acc = rnd(m, n, seed=5)
+    want = acc + a @ b
+    close(nv.gemm(a, b, out=acc, accumulate=True), want)
     out = torch.zeros(n, device=DEV)
     nv.col_sum(b, out)
     close(out, b.sum(0))
