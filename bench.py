@@ -260,6 +260,7 @@ def main() -> None:
                 "reference_worker_batch": 256, "seq_len": None, "image": "32x32x3", "optimizer": args.optimizer,
                 "parallelism": f"dp{world}", "hip_graph": graph, "allreduce": args.allreduce if world > 1 else "none", "grad_buckets": len(ranges),
                 "kernels_per_step": step.kernel_count, "final_loss": round(loss, 4),
+                "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
                 "baseline": "CPU reference floor (bench/cpu_floor.json); the reference publishes no numbers",
             },
         }))
