@@ -118,6 +118,61 @@ class DataSet:
         return self._images[start:end], self._labels[start:end]
 
 
+class GpuBatcher:
+    """The training set resident on the device: `next_batch_into` fills the step program's input
+    buffers with the batch `DataSet.next_batch` would return next, without touching the host.
+
+    The data set keeps its (already shuffled) order on the device; a batch is a contiguous slice
+    copied device-to-device, and the epoch-wrap reshuffle (the same seed-448 permutation every
+    time, applied to the current order; reference: DistributedLeNet/src/mnist_data.py:120-128) is
+    one gather on the device. In fake-data mode batches are drawn on the device from a generator
+    seeded by the position in the stream, so every worker still sees the same sequence."""
+
+    def __init__(self, dataset: DataSet, device):
+        import torch
+
+        self._torch = torch
+        self.device = torch.device(device)
+        self.fake = dataset.fake_data
+        self.num_examples = dataset.num_examples
+        self.index_in_epoch = dataset._index_in_epoch
+        self.epochs_completed = dataset.epochs_completed
+        if self.fake:
+            self._gen = torch.Generator(device=self.device)
+        else:
+            self.images = torch.as_tensor(np.ascontiguousarray(dataset.images), dtype=torch.float32).to(self.device)
+            self.labels = torch.as_tensor(np.ascontiguousarray(dataset.labels)).to(self.device)
+            np.random.seed(SHUFFLE_SEED)
+            perm = np.arange(self.num_examples)
+            np.random.shuffle(perm)
+            self._perm = torch.as_tensor(perm).to(self.device)
+
+    def next_batch_into(self, images_out, labels_out) -> None:
+        torch = self._torch
+        b = images_out.shape[0]
+        if self.fake:
+            self._gen.manual_seed(self.index_in_epoch + 7919 * self.epochs_completed)
+            self.index_in_epoch += b
+            if self.index_in_epoch > self.num_examples:
+                self.epochs_completed += 1
+                self.index_in_epoch = b
+            images_out.uniform_(-0.5, 0.5, generator=self._gen)
+            labels_out.copy_(torch.randint(0, 10, (b,), device=self.device, generator=self._gen))
+            return
+        start = self.index_in_epoch
+        self.index_in_epoch += b
+        if self.index_in_epoch > self.num_examples:
+            assert b <= self.num_examples
+            self.epochs_completed += 1
+            self.images = self.images.index_select(0, self._perm)
+            self.labels = self.labels.index_select(0, self._perm)
+            start = 0
+            self.index_in_epoch = b
+        end = self.index_in_epoch
+        images_out.copy_(self.images[start:end].reshape(images_out.shape))
+        labels_out.copy_(self.labels[start:end])
+
+
 def read_data_sets(train_dir: str, fake_data: bool = False, worker_id: int = -1, n_workers: int = -1) -> Datasets:
     """`worker_id` / `n_workers` are accepted for signature parity and, like the reference, unused."""
     if fake_data:

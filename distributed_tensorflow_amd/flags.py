@@ -234,7 +234,7 @@ def define_extension_flags() -> None:
     DEFINE_boolean("weighted_grads_method", False, "Least-squares weighted gradient aggregation with simulated worker kills")
     DEFINE_integer("grad_buckets", 3, "Gradient all-reduce buckets overlapped with the backward pass")
     DEFINE_boolean("reduce_scatter", False, "Shard the optimizer: reduce-scatter gradients, all-gather parameters")
-    DEFINE_boolean("gpu_data_pipeline", True, "ResNet on a GPU: keep the dataset in HBM and crop + whiten on the device")
+    DEFINE_boolean("gpu_data_pipeline", True, "On a GPU keep the training set in HBM (ResNet: crop + whiten on the device; LeNet: batches sliced device-to-device)")
     DEFINE_string("allreduce_impl", "rccl", "Gradient all-reduce: rccl (RCCL collectives) or p2p (hand-written two-shot kernel over peer-mapped HBM)")
     DEFINE_boolean("hip_graph", True, "Replay the training step as a hipGraph")
     DEFINE_integer("inject_straggler_ms", 0, "Fault injection: delay the listed replicas by this many ms per step")

@@ -60,6 +60,15 @@ class _MnistFeed:
     def next(self):
         return self.sets.train.next_batch(self.batch_size)
 
+    def to_gpu(self, device) -> None:
+        """Moves the training set into HBM; from then on `feed_into` slices batches on the GPU."""
+        self.gpu_batcher = mnist_data.GpuBatcher(self.sets.train, device)
+
+    def feed_into(self, replica) -> None:
+        st = replica.step
+        with replica.stream_ctx():
+            self.gpu_batcher.next_batch_into(st.images, st.labels)
+
 
 class _CifarFeed:
     def __init__(self, data_dir: str, batch_size: int, padding: int, num_examples: int, seed: Optional[int]):
@@ -159,8 +168,9 @@ def train(flags, model: str) -> Dict:
         momentum=flags.momentum, weight_decay=flags.weight_decay if flags.optimizer == "momentum" else 0.0,
         num_buckets=buckets, use_graph=flags.hip_graph,
     )
-    # ResNet on the GPU: the dataset lives in HBM and augmentation is one kernel per step
-    gpu_feed = model == "resnet" and hasattr(replica, "step") and flags.gpu_data_pipeline
+    # On the GPU the dataset lives in HBM: ResNet crops + whitens with one kernel per step, LeNet
+    # slices its batches device-to-device
+    gpu_feed = hasattr(replica, "step") and flags.gpu_data_pipeline
     if gpu_feed:
         feed.to_gpu(replica.device)
     saver = Saver(replica.arena, flags.optimizer, flags.checkpoint_names)
@@ -216,6 +226,7 @@ def train(flags, model: str) -> Dict:
         for r in range(world):
             board.put_tokens(r, 1, global_step)   # init tokens (reference: get_init_tokens_op)
     aborted_steps = excluded_steps = 0
+    window_start, window_steps = time.time(), 0   # since the last training line (log_every > 1)
 
     while not sv.should_stop():
         log.info("A new iteration...")
@@ -279,8 +290,13 @@ def train(flags, model: str) -> Dict:
             timeline.write(train_dir, step)
         if step > flags.max_steps or (async_mode and board.should_stop()):
             break
-        duration = time.time() - start_time
+        window_steps += 1
         if log_now:
+            # With log_every > 1 the host runs ahead of the GPU between lines and the loss
+            # read-back above waits for all of it, so the rate is taken over the whole window.
+            now = time.time()
+            duration = (now - window_start) / window_steps if flags.log_every > 1 else now - start_time
+            window_start, window_steps = now, 0
             examples_per_sec = batch_size / float(duration)
             log.info(TRAIN_LINE % (rank, datetime.now(), step, loss_value, examples_per_sec, duration))
         if is_chief and summary_writer is not None and next_summary_time < time.time():

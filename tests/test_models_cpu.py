@@ -154,3 +154,34 @@ def test_cifar_pipeline(tmp_path):
         cifar._read_one_batch(str(tmp_path / "evil"))
     sx, sy = cifar.prepare_train_data("", 2, num_synthetic=64)
     assert sx.shape == (64, 36, 36, 3)
+
+
+def test_mnist_device_batcher_follows_the_host_dataset():
+    """The device-resident batcher returns exactly the batches DataSet.next_batch returns,
+    across epoch wraps (same seed-448 reshuffle of the current order)."""
+    import numpy as np
+    import torch
+
+    from distributed_tensorflow_amd.data.mnist import DataSet, GpuBatcher
+
+    rng = np.random.RandomState(0)
+    images = rng.rand(50, 28, 28, 1).astype(np.float32)
+    labels = rng.randint(0, 10, 50).astype(np.int64)
+    host = DataSet(images.copy(), labels.copy())
+    dev = GpuBatcher(DataSet(images.copy(), labels.copy()), "cpu")
+    xb = torch.empty(16, 28, 28, 1)
+    yb = torch.empty(16, dtype=torch.int32)
+    for _ in range(11):   # 3.5 epochs
+        hx, hy = host.next_batch(16)
+        dev.next_batch_into(xb, yb)
+        assert np.array_equal(xb.numpy(), hx) and np.array_equal(yb.numpy(), hy.astype(np.int32))
+    assert dev.epochs_completed == host.epochs_completed == 3
+    # fake-data mode: same stream on every worker, fresh batch per step
+    f1, f2 = GpuBatcher(DataSet(None, None, True, 100), "cpu"), GpuBatcher(DataSet(None, None, True, 100), "cpu")
+    x1, x2, y1, y2 = torch.empty(8, 28, 28, 1), torch.empty(8, 28, 28, 1), torch.empty(8, dtype=torch.int32), torch.empty(8, dtype=torch.int32)
+    f1.next_batch_into(x1, y1)
+    f2.next_batch_into(x2, y2)
+    assert torch.equal(x1, x2) and torch.equal(y1, y2) and float(x1.min()) >= -0.5 and float(x1.max()) <= 0.5
+    prev = x1.clone()
+    f1.next_batch_into(x1, y1)
+    assert not torch.equal(prev, x1)
