@@ -289,6 +289,11 @@ PYBIND11_MODULE(_hip, m) {
     P(x, const float); P(out, float); V(n_rows); V(C);
     col_sum(a, as_stream(stream));
   });
+  m.def("tf_histogram", [](const py::dict& d, uint64_t stream) {
+    HistogramArgs a{};
+    P(x, const float); V(n); P(limits, const double); V(nb); P(counts, unsigned long long); P(moments, double); P(minmax, int);
+    tf_histogram(a, as_stream(stream));
+  });
   m.def("zero_count", [](const py::dict& d, uint64_t stream) {
     ZeroFracArgs a{};
     P(x, const float); P(zeros, unsigned long long); V(n);

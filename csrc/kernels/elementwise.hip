@@ -212,6 +212,57 @@ __global__ __launch_bounds__(256) void zero_count_kernel(ZeroFracArgs a) {
   if ((threadIdx.x & 63) == 0 && s > 0.f) atomicAdd(a.zeros, (unsigned long long)(s + 0.5f));
 }
 
+// Privatised histogram: the limits and one count per bucket live in LDS (dynamic: nb doubles +
+// nb counters), a value's bucket is found by binary search, block totals go out with one atomic
+// per non-empty bucket.
+__device__ __forceinline__ int float_order_key(float f) {
+  const int b = __float_as_int(f);
+  return b >= 0 ? b : b ^ 0x7fffffff;
+}
+__global__ __launch_bounds__(256) void tf_histogram_kernel(HistogramArgs a) {
+  extern __shared__ __align__(8) unsigned char hist_smem[];
+  double* lim = reinterpret_cast<double*>(hist_smem);
+  unsigned int* cnt = reinterpret_cast<unsigned int*>(lim + a.nb);
+  for (int i = threadIdx.x; i < a.nb; i += 256) {
+    lim[i] = a.limits[i];
+    cnt[i] = 0u;
+  }
+  __syncthreads();
+  double s1 = 0.0, s2 = 0.0;
+  int kmin = 0x7fffffff, kmax = (int)0x80000000;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+    const float f = a.x[i];
+    const double v = (double)f;
+    int lo = 0, hi = a.nb - 1;   // first index with lim[idx] > v (the last limit is DBL_MAX)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (lim[mid] > v) hi = mid; else lo = mid + 1;
+    }
+    atomicAdd(&cnt[lo], 1u);
+    s1 += v;
+    s2 += v * v;
+    const int k = float_order_key(f);
+    kmin = min(kmin, k);
+    kmax = max(kmax, k);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_xor(s1, off, 64);
+    s2 += __shfl_xor(s2, off, 64);
+    kmin = min(kmin, __shfl_xor(kmin, off, 64));
+    kmax = max(kmax, __shfl_xor(kmax, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&a.moments[0], s1);
+    atomicAdd(&a.moments[1], s2);
+    atomicMin(&a.minmax[0], kmin);
+    atomicMax(&a.minmax[1], kmax);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.nb; i += 256)
+    if (cnt[i]) atomicAdd(&a.counts[i], (unsigned long long)cnt[i]);
+}
+
 // One block per output image: two-pass mean / std over the cropped H*W*C values, then
 // (x - mean) / max(std, 1/sqrt(H*W*C)).
 __global__ __launch_bounds__(256) void crop_whiten_kernel(CropWhitenArgs a) {
@@ -338,6 +389,12 @@ void col_sum(const ColSumArgs& a, hipStream_t stream) {
 }
 void zero_count(const ZeroFracArgs& a, hipStream_t stream) {
   launch("zero_count", zero_count_kernel, dim3(flat_blocks(a.n)), dim3(256), 0, stream, a);
+}
+void tf_histogram(const HistogramArgs& a, hipStream_t stream) {
+  if (a.nb < 1 || a.nb > 4096) throw std::runtime_error("tf_histogram: 1..4096 buckets");
+  int blocks = flat_blocks(a.n);
+  if (blocks > 1024) blocks = 1024;   // every block ends with up to nb atomics
+  launch("tf_histogram", tf_histogram_kernel, dim3(blocks), dim3(256), (size_t)a.nb * 12, stream, a);
 }
 void crop_whiten(const CropWhitenArgs& a, hipStream_t stream) {
   launch("crop_whiten", crop_whiten_kernel, dim3(a.B), dim3(256), 0, stream, a);

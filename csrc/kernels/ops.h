@@ -184,6 +184,13 @@ struct Top1Args { const float* logits; const int* labels; int* correct; int B, K
 void top1_count(const Top1Args& a, hipStream_t stream);
 struct ZeroFracArgs { const float* x; unsigned long long* zeros; long long n; };
 void zero_count(const ZeroFracArgs& a, hipStream_t stream);
+// Histogram over caller-supplied ascending bucket limits (tf.summary.histogram semantics: a value
+// lands in the first bucket whose limit is greater than it; reference: activation_summary,
+// DistributedResNet/src/resnet.py:13-20). counts [nb] += per-bucket counts; moments [2] += (sum,
+// sum of squares); minmax [2] = order-preserving integer keys of the minimum / maximum (start them
+// at INT_MAX / INT_MIN; decode with histogram_key_to_float).
+struct HistogramArgs { const float* x; long long n; const double* limits; int nb; unsigned long long* counts; double* moments; int* minmax; };
+void tf_histogram(const HistogramArgs& a, hipStream_t stream);
 
 // CIFAR augmentation on device: random crop from the zero-padded image + per-image whitening
 // reference: DistributedResNet/src/cifar10_input.py:111-143

@@ -165,16 +165,23 @@ class ResNetHipStep(StepProgramBase):
         st = nv.BnState(self.stats[o:o + n], self.arena.param(gamma), self.arena.param(beta), count, BN_EPSILON)
         return _Bn(st, self.stats[o + n:o + 2 * n], gamma, beta)
 
-    def activation_sparsity(self) -> Dict[str, float]:
-        """Zero fraction of every ReLU output (tf.nn.zero_fraction in the reference's
-        activation_summary, DistributedResNet/src/resnet.py:13-20). The normalised activations
-        are never materialised by the step, so they are recomputed here (summary cadence only)."""
+    def _summary_items(self):
         items = [("conv0", self.c0, self.bn0)]
         for k in range(len(self.blocks)):
             items.append((f"block{k}/conv1", self.c1[k], self.bn2[k]))
             nxt = self.bn1[k + 1] if k + 1 < len(self.blocks) else self.bnf
             items.append((f"block{k}/out", self.y[k], nxt))
-        return {f"{name}/sparsity": nv.zero_fraction(nv.bn_apply(t, bn.fwd, relu=True)) for name, t, bn in items}
+        return items
+
+    def activation_sparsity(self) -> Dict[str, float]:
+        """Zero fraction of every ReLU output (tf.nn.zero_fraction in the reference's
+        activation_summary, DistributedResNet/src/resnet.py:13-20). The normalised activations
+        are never materialised by the step, so they are recomputed here (summary cadence only)."""
+        return {f"{name}/sparsity": nv.zero_fraction(nv.bn_apply(t, bn.fwd, relu=True)) for name, t, bn in self._summary_items()}
+
+    def activation_histograms(self) -> Dict[str, dict]:
+        """tf.summary.histogram of the same activations (the other half of activation_summary)."""
+        return {f"{name}/activations": nv.tf_histogram(nv.bn_apply(t, bn.fwd, relu=True)) for name, t, bn in self._summary_items()}
 
     def _wgrad(self, x: torch.Tensor, dout: torch.Tensor, name: str, stride: int, in_bn=None) -> None:
         a = self.arena

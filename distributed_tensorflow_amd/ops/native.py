@@ -9,7 +9,7 @@ instead of silently falling back to PyTorch ops.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional
+from typing import Dict, Optional
 
 import torch
 
@@ -712,6 +712,40 @@ def zero_fraction(x) -> float:
     z = torch.zeros(1, device=x.device, dtype=torch.int64)
     hip().zero_count(dict(x=_chk(x, "x"), zeros=z.data_ptr(), n=x.numel()), stream())
     return float(z.item()) / max(1, x.numel())
+
+
+_HIST_LIMITS: Dict = {}
+
+
+def tf_histogram(x) -> dict:
+    """tf.summary.histogram of a device tensor: dict(min, max, num, sum, sum_squares,
+    bucket_limit, bucket) with TensorFlow's default buckets and its run-length compression of
+    empty buckets (host statement: utils/summary.py::histogram_of)."""
+    require()
+    import numpy as np
+
+    from ..utils import summary as sm
+
+    limits_np = sm.default_bucket_limits()
+    key = str(x.device)
+    if key not in _HIST_LIMITS:
+        _HIST_LIMITS[key] = torch.as_tensor(limits_np).to(x.device)
+    limits = _HIST_LIMITS[key]
+    nb = limits.numel()
+    counts = torch.zeros(nb, device=x.device, dtype=torch.int64)
+    moments = torch.zeros(2, device=x.device, dtype=torch.float64)
+    minmax = torch.tensor([2**31 - 1, -2**31], device=x.device, dtype=torch.int32)
+    flat = x.reshape(-1)
+    hip().tf_histogram(dict(x=_chk(flat, "x"), n=flat.numel(), limits=_chk(limits, "limits", torch.float64), nb=nb,
+                            counts=_chk(counts, "counts", torch.int64), moments=_chk(moments, "moments", torch.float64),
+                            minmax=_chk(minmax, "minmax", torch.int32)), stream())
+    keys = minmax.cpu().numpy().astype(np.int32)
+    bits = np.where(keys >= 0, keys, keys ^ np.int32(0x7FFFFFFF)).astype(np.int32)
+    lo, hi = bits.view(np.float32)
+    mom = moments.cpu().numpy()
+    bl, bc = sm.compress_histogram(limits_np, counts.cpu().numpy().astype(np.float64))
+    return {"min": float(lo), "max": float(hi), "num": float(flat.numel()), "sum": float(mom[0]), "sum_squares": float(mom[1]),
+            "bucket_limit": bl, "bucket": bc}
 
 
 def crop_whiten(src, index=None, offs=None, out_hw=None, whiten=True, out=None):

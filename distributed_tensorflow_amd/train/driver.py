@@ -307,6 +307,9 @@ def train(flags, model: str) -> Dict:
             # DistributedResNet/src/resnet.py:13-20)
             scalars.update(getattr(getattr(replica, "step", None), "activation_sparsity", dict)())
             summary_writer.add_scalars(scalars, step)
+            histograms = getattr(getattr(replica, "step", None), "activation_histograms", dict)()
+            if histograms:
+                summary_writer.add_histograms(histograms, step)
             log.info("Finished running Summary operation.")
             next_summary_time += flags.save_summaries_secs
         sv.maybe_save(step, replica.updates_applied)

@@ -544,6 +544,20 @@ def test_conv1_pool_fused_forward_and_backward(b):
     close(db2, br.grad, tol=5e-4)
 
 
+def test_tf_histogram_matches_host_statement():
+    from distributed_tensorflow_amd.utils import summary as sm
+
+    x = rnd(3, 17, 9, 16, scale=3.0)
+    x = torch.relu(x)            # many exact zeros, like an activation
+    x.view(-1)[5] = 1e-13        # below the smallest positive limit
+    x.view(-1)[6] = -2.5
+    got = nv.tf_histogram(x)
+    want = sm.histogram_of(x.cpu().numpy())
+    assert got["bucket_limit"] == want["bucket_limit"] and got["bucket"] == want["bucket"]
+    assert got["num"] == want["num"] and got["min"] == want["min"] and got["max"] == want["max"]
+    assert abs(got["sum"] - want["sum"]) < 1e-6 * abs(want["sum"]) and abs(got["sum_squares"] - want["sum_squares"]) < 1e-6 * want["sum_squares"]
+
+
 def test_maxpool_same():
     for shape in [(3, 28, 28, 32), (3, 14, 14, 64), (2, 7, 7, 8)]:
         x = rnd(*shape)

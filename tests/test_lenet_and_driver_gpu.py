@@ -68,10 +68,23 @@ def test_driver_trains_resnet_on_gpu_and_evaluator_scores_it(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "DistributedResNet/src/resnet_distributed_train.py", "--synthetic_data", "--batch_size=32",
                         "--num_residual_blocks=1", "--max_steps=12", f"--train_dir={d}", "--initial_learning_rate=0.001",
-                        "--log_every=4"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+                        "--log_every=4", "--should_summarize=true", "--save_summaries_secs=0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     steps = [int(m.group(1)) for m in (re.match(r".*step (\d+), loss = ", l) for l in r.stderr.splitlines()) if m]
     assert steps and steps[-1] >= 9
+    # activation summaries (sparsity scalars + histograms) of every ReLU output, computed on the GPU
+    import glob
+
+    from distributed_tensorflow_amd.utils.summary import read_events, read_histograms
+
+    (ev,) = glob.glob(os.path.join(d, "events.out.tfevents.*"))
+    scalars = list(read_events(ev))
+    assert scalars and "loss" in scalars[-1][1] and any(k.endswith("/sparsity") for k in scalars[-1][1])
+    histos = list(read_histograms(ev))
+    assert histos and "conv0/activations" in histos[-1][1]
+    h = histos[-1][1]["conv0/activations"]
+    assert h["num"] == 32 * 32 * 32 * 16 and h["min"] == 0.0 and sum(h["bucket"]) == h["num"]
     e = subprocess.run([sys.executable, "DistributedResNet/src/resnet_eval.py", "--synthetic_data", "--num_residual_blocks=1",
                         f"--checkpoint_dir={d}", f"--eval_dir={tmp_path / 'eval'}", "--run_once=true"],
                        capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)

@@ -185,3 +185,26 @@ def test_mnist_device_batcher_follows_the_host_dataset():
     prev = x1.clone()
     f1.next_batch_into(x1, y1)
     assert not torch.equal(prev, x1)
+
+
+def test_histogram_summary_round_trip(tmp_path):
+    """Histogram events: TensorFlow's default buckets, empty runs collapsed, readable back."""
+    import numpy as np
+
+    from distributed_tensorflow_amd.utils import summary as sm
+
+    limits = sm.default_bucket_limits()
+    assert limits[0] < -1e300 and limits[-1] > 1e300 and 0.0 in limits and np.all(np.diff(limits) > 0)
+    v = np.array([0.0, 0.0, 1.0, 1.05, -3.0, 5e-13], dtype=np.float32)
+    h = sm.histogram_of(v)
+    assert h["num"] == 6 and h["min"] == -3.0 and sum(h["bucket"]) == 6
+    # a value lands in the first bucket whose limit exceeds it: zeros go to the bucket ending at 1e-12
+    i = h["bucket_limit"].index(1.0e-12)
+    assert h["bucket"][i] == 3          # the two zeros and 5e-13
+    assert len(h["bucket"]) < 16        # empty runs are collapsed
+    w = sm.FileWriter(str(tmp_path))
+    w.add_scalars({"loss": 0.25}, 3)
+    w.add_histograms({"conv0/activations": h}, 3)
+    w.close()
+    assert list(sm.read_events(w.path)) == [(3, {"loss": 0.25})]
+    assert list(sm.read_histograms(w.path)) == [(3, {"conv0/activations": h})]
