@@ -84,9 +84,7 @@ def bench_policy(args) -> None:
     labels = torch.randint(0, 10, (args.batch,), device=comm.device)
     replica.load_batch(images, labels)
     for i in range(args.warmup):
-        r = step_fn(i)
-        if os.environ.get("DTF_BENCH_DEBUG"):
-            print("warmup", i, r, replica.loss_value(), file=sys.stderr, flush=True)
+        step_fn(i)
     replica.synchronize()
     comm.barrier()
     torch.cuda.synchronize()
@@ -101,8 +99,6 @@ def bench_policy(args) -> None:
     if args.mode == "async":
         shards.drain(30.0)
         detail["async_stats"] = vars(shards.stats)
-        if os.environ.get("DTF_BENCH_DEBUG"):
-            print("after drain", final_loss, replica.loss_value(), file=sys.stderr, flush=True)
     t = torch.tensor([dt], device=comm.device, dtype=torch.float64)
     if world > 1:
         import torch.distributed as dist
