@@ -51,7 +51,7 @@ def bench_policy(args) -> None:
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X")
-    comm = Communicator.from_env(backend=args.backend)
+    comm = Communicator.from_env(backend=args.backend, force_group=args.rehearse_collectives)
     world = comm.world
     torch.manual_seed(1234 + comm.rank)
     replica = HipReplica("resnet", args.batch, num_residual_blocks=MODELS[args.model], optimizer=args.optimizer,
@@ -155,6 +155,9 @@ def main() -> None:
                          "--aggregate gradients (masked all-reduce); async = staleness-bounded parameter shards")
     ap.add_argument("--aggregate", type=int, default=0, help="backup mode: gradients per update (default N-1)")
     ap.add_argument("--staleness", type=int, default=4, help="async mode: staleness bound")
+    ap.add_argument("--rehearse-collectives", action="store_true",
+                    help="one rank only: create the process group anyway and run the bucketed step with its all-reduces "
+                         "through the backend (exercises the multi-GPU code path of the step on a single GPU)")
     args = ap.parse_args()
     if args.mode != "sync":
         return bench_policy(args)
@@ -165,8 +168,9 @@ def main() -> None:
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; for the CPU floor run bench/cpu_reference.py")
-    comm = Communicator.from_env(backend=args.backend)
+    comm = Communicator.from_env(backend=args.backend, force_group=args.rehearse_collectives)
     world = comm.world
+    multi = world > 1 or args.rehearse_collectives
     if world != args.gpus and comm.is_chief:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     n = MODELS[args.model]
@@ -174,7 +178,7 @@ def main() -> None:
 
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        step = ResNetHipStep(n, args.batch, optimizer=args.optimizer, num_buckets=args.buckets if world > 1 else 1)
+        step = ResNetHipStep(n, args.batch, optimizer=args.optimizer, num_buckets=args.buckets if multi else 1)
         # identical initial parameters on every replica
         comm.broadcast(step.arena.params, 0)
         if args.allreduce == "p2p":
@@ -185,7 +189,7 @@ def main() -> None:
         mode = "off" if args.no_graph else args.graph
         graph = (mode == "on") or (mode == "auto" and not step.side_stream)
         if graph:
-            step.instantiate(per_segment=world > 1)
+            step.instantiate(per_segment=multi)
         nseg = step.num_segments
         ranges = step.bucket_ranges
         grads = step.arena.grads
@@ -196,7 +200,7 @@ def main() -> None:
             t_global += 1
             step.set_hyper(lr_t=ref.adam_lr_t(args.lr, t_global) if args.optimizer == "adam" else args.lr,
                            grad_scale=1.0 / world, momentum=0.9, weight_decay=2e-4)
-            if world == 1:
+            if not multi:
                 step.run(-1, graph)
                 return
             for i in range(nseg - 1):
@@ -228,7 +232,7 @@ def main() -> None:
         p50 = per_step[len(per_step) // 2] if per_step else float("nan")
 
     t = torch.tensor([dt], device=comm.device, dtype=torch.float64)
-    if world > 1:
+    if multi:
         import torch.distributed as dist
 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -254,7 +258,7 @@ def main() -> None:
             "config": {
                 "model": args.model, "global_batch": args.batch * world, "per_gpu_batch": args.batch,
                 "reference_worker_batch": 256, "seq_len": None, "image": "32x32x3", "optimizer": args.optimizer,
-                "parallelism": f"dp{world}", "hip_graph": graph, "allreduce": args.allreduce if world > 1 else "none", "grad_buckets": len(ranges),
+                "parallelism": f"dp{world}", "hip_graph": graph, "allreduce": args.allreduce if multi else "none", "grad_buckets": len(ranges),
                 "kernels_per_step": step.kernel_count, "final_loss": round(loss, 4),
                 "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
                 "baseline": "CPU reference floor (bench/cpu_floor.json); the reference publishes no numbers",
@@ -263,5 +267,19 @@ def main() -> None:
     comm.close()
 
 
+def _run_with_clean_stdout() -> None:
+    """Libraries below us may print to the process's stdout (RCCL prints a version banner there
+    when NCCL_DEBUG is set); the contract is ONE JSON line on stdout. So file descriptor 1 points
+    at stderr while the benchmark runs, and Python's sys.stdout keeps the real stdout."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(real, "w", buffering=1)
+    try:
+        main()
+    finally:
+        sys.stdout.flush()
+
+
 if __name__ == "__main__":
-    main()
+    _run_with_clean_stdout()

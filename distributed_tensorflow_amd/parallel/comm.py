@@ -33,16 +33,22 @@ class CommInfo:
 class Communicator:
     """Thin owner of the default process group (or a no-op for a single replica)."""
 
-    def __init__(self, info: CommInfo, owns_group: bool):
+    def __init__(self, info: CommInfo, owns_group: bool, collectives: Optional[bool] = None):
         self.info = info
         self._owns = owns_group
+        # False: a single replica, every collective is a no-op. A one-rank process group can be
+        # forced on (from_env(force_group=True)) to run the real backend's code path on one GPU.
+        self._collectives = info.world > 1 if collectives is None else collectives
         self._pending: List = []
         self.p2p = None   # optional hand-written peer-to-peer all-reduce (parallel/p2p.py)
 
     # -- construction ----------------------------------------------------------------------------
     @classmethod
-    def from_env(cls, backend: Optional[str] = None, device: Optional[str] = None, timeout_s: int = 600) -> "Communicator":
-        """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torchrun contract)."""
+    def from_env(cls, backend: Optional[str] = None, device: Optional[str] = None, timeout_s: int = 600,
+                 force_group: bool = False) -> "Communicator":
+        """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torchrun contract).
+        force_group: create the process group even for one rank, so that the collectives go
+        through the backend (rehearsal of the multi-GPU code path on a single GPU)."""
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -55,7 +61,7 @@ class Communicator:
         else:
             dev = torch.device("cpu")
         owns = False
-        if world > 1:
+        if world > 1 or force_group:
             if not dist.is_initialized():
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", "29500")
@@ -64,7 +70,7 @@ class Communicator:
                     kwargs["device_id"] = dev
                 dist.init_process_group(**kwargs)
                 owns = True
-        return cls(CommInfo(rank, world, local_rank, backend, dev), owns)
+        return cls(CommInfo(rank, world, local_rank, backend, dev), owns, world > 1 or force_group)
 
     @classmethod
     def single(cls, device: str | torch.device = "cpu") -> "Communicator":
@@ -92,7 +98,7 @@ class Communicator:
         """SUM all-reduce of one contiguous bucket; returns immediately. On RCCL the collective
         runs on the process group's own stream, ordered after everything already enqueued on the
         current stream, so later kernels on the current stream overlap with it."""
-        if self.world == 1:
+        if not self._collectives:
             return
         if self.p2p is not None and flat.is_cuda:
             self.p2p.all_reduce(flat)   # stream-ordered kernel on the current stream
@@ -113,7 +119,7 @@ class Communicator:
         self._pending.clear()
 
     def all_reduce(self, t: torch.Tensor, op=dist.ReduceOp.SUM) -> torch.Tensor:
-        if self.world > 1:
+        if self._collectives:
             dist.all_reduce(t, op=op)
         return t
 
@@ -121,7 +127,7 @@ class Communicator:
         """Reduce-scatter over uneven contiguous shards: rank r ends up with the SUM of
         flat[bounds[r]] (returned as a view of `flat`)."""
         lo, hi = bounds[self.rank]
-        if self.world == 1:
+        if not self._collectives:
             return flat[lo:hi]
         if flat.is_cuda and self.info.backend == "gloo":
             torch.cuda.current_stream().synchronize()
@@ -140,7 +146,7 @@ class Communicator:
 
     def all_gather_flat(self, flat: torch.Tensor, bounds: Sequence[Tuple[int, int]]) -> None:
         """Every rank broadcasts its shard flat[bounds[rank]] into the same range on all ranks."""
-        if self.world == 1:
+        if not self._collectives:
             return
         if flat.is_cuda and self.info.backend == "gloo":
             torch.cuda.current_stream().synchronize()
@@ -153,7 +159,7 @@ class Communicator:
             w.wait()
 
     def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
-        if self.world > 1:
+        if self._collectives:
             if t.is_cuda and self.info.backend == "gloo":
                 torch.cuda.current_stream().synchronize()
                 host = t.detach().cpu()
@@ -164,14 +170,14 @@ class Communicator:
         return t
 
     def barrier(self) -> None:
-        if self.world > 1:
+        if self._collectives:
             if self.info.backend == "nccl":
                 dist.barrier(device_ids=[self.info.device.index])
             else:
                 dist.barrier()
 
     def all_gather_object(self, obj):
-        if self.world == 1:
+        if not self._collectives:
             return [obj]
         out = [None] * self.world
         dist.all_gather_object(out, obj)

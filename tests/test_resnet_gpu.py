@@ -178,3 +178,25 @@ def test_backward_variants_agree(monkeypatch, env):
     scale = base.abs().max().item()
     assert (got - base).abs().max().item() < 2e-4 * scale
     assert (replay - got).abs().max().item() < 2e-4 * scale   # hipGraph replay of the forked program
+
+
+def test_bench_contract_one_json_line_through_the_rccl_path():
+    """bench.py with a one-rank RCCL process group: the bucketed step issues its all-reduces
+    through the real backend, and stdout carries exactly one JSON line (RCCL's banner and any
+    other library chatter go to stderr)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29713", NCCL_DEBUG="VERSION", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for extra in ([], ["--mode", "sharded"]):
+        r = subprocess.run([sys.executable, "bench.py", "--rehearse-collectives", "--model", "resnet8", "--batch", "32",
+                            "--steps", "3", "--warmup", "1"] + extra, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["dtype"] == "fp32"
+        assert d["config"]["final_loss"] == d["config"]["final_loss"]   # not NaN
