@@ -308,6 +308,10 @@ def tf_ec2_run(argv: List[str], configuration: Cfg, **kw):
 
 def main() -> None:
     argv = list(sys.argv)
+    if len(argv) < 2 or argv[1] in ("-h", "--help", "help"):
+        print(__doc__)
+        print("usage: node_launch.py [--cfg FILE] [--out_root DIR] [--max_workers N] <command> [args] [-- extra entry-script flags]")
+        return
     configuration = DEFAULT_CFG
     extra: List[str] = []
     kw = {}
