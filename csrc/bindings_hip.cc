@@ -110,6 +110,17 @@ PYBIND11_MODULE(_hip, m) {
     conv5x5_pack(a, as_stream(stream));
   });
   m.def("conv5x5_tile_supported", &conv5x5_tile_supported);
+  m.def("conv5x5_wgrad", [](const py::dict& d, uint64_t stream) {
+    Conv5x5WgradArgs a{};
+    P(x, const float); P(dy, const float); P(dw, float); V(slot_stride); V(B); P(partials, float);
+    conv5x5_wgrad(a, as_stream(stream));
+  });
+  m.def("conv5x5_wgrad_parts", &conv5x5_wgrad_parts);
+  m.def("partial_sum", [](const py::dict& d, uint64_t stream) {
+    PartialSumArgs a{};
+    P(y, float); P(ws, const float); V(n); V(parts); V(stride);
+    partial_sum(a, as_stream(stream));
+  });
   m.def("conv1_pool_fwd", [](const py::dict& d, uint64_t stream) {
     Conv1PoolFwdArgs a{};
     P(x, const float); P(w, const float); P(bias, const float); P(p, float); P(arg, unsigned char); V(B);

@@ -152,6 +152,21 @@ struct Conv5x5PackArgs {
   float* out;       // [25][Cout][Cin]
   int Cin, Cout;
 };
+// Filter gradient of that layer: dw [25][32][64] (HWIO) += sum_p x[p + tap] (x) dy[p]; with
+// slot_stride != 0 into the copy of the workgroup's XCD (dw + slot * slot_stride).
+struct Conv5x5WgradArgs {
+  const float* x;    // [B,14,14,32]
+  const float* dy;   // [B,14,14,64]
+  float* dw;
+  int slot_stride;
+  int B;
+  // Non-null: workgroup b stores its whole partial result at partials + b * 25*32*64 with plain
+  // stores instead of adding it to dw (no atomics; sum the conv5x5_wgrad_parts(B) copies with
+  // partial_sum). Every element is written, so the buffer needs no clearing.
+  float* partials;
+};
+int conv5x5_wgrad_parts(int B);
+void conv5x5_wgrad(const Conv5x5WgradArgs& a, hipStream_t stream);
 bool conv5x5_tile_supported(int H, int W, int Cin, int Cout);
 void conv5x5_tile(const Conv5x5Args& a, hipStream_t stream);
 void conv5x5_pack(const Conv5x5PackArgs& a, hipStream_t stream);

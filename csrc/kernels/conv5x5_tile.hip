@@ -130,15 +130,28 @@ __global__ __launch_bounds__(256) void conv5x5_tile_kernel(Conv5x5Args a) {
         const float* base = lds + toff;
 #pragma unroll
         for (int j = 0; j < G::KG; ++j) {
+          // four pixel tiles at a time, so that consecutive MFMAs write different accumulators.
+          // A wave whose last pixel tile lies beyond the image multiplies a clamped copy of the
+          // last pixel instead of branching (the result is not stored).
 #pragma unroll
-          for (int i = 0; i < G::NTW; ++i) {
-            // a wave whose last pixel tile lies beyond the image multiplies a clamped copy of the
-            // last pixel instead of branching (the result is not stored)
-            const float4 b = *reinterpret_cast<const float4*>(base + boff[i] + 16 * j);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[j].x, b.x, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[j].y, b.y, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[j].z, b.z, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[j].w, b.w, acc[i], 0, 0, 0);
+          for (int i0 = 0; i0 < G::NTW; i0 += 4) {
+            constexpr int kGroup = 4;
+            float4 b[kGroup];
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u)
+              if (i0 + u < G::NTW) b[u] = *reinterpret_cast<const float4*>(base + boff[i0 + u] + 16 * j);
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u)
+              if (i0 + u < G::NTW) acc[i0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[j].x, b[u].x, acc[i0 + u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u)
+              if (i0 + u < G::NTW) acc[i0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[j].y, b[u].y, acc[i0 + u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u)
+              if (i0 + u < G::NTW) acc[i0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[j].z, b[u].z, acc[i0 + u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u)
+              if (i0 + u < G::NTW) acc[i0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wcur[j].w, b[u].w, acc[i0 + u], 0, 0, 0);
           }
         }
 #pragma unroll
@@ -170,6 +183,139 @@ __global__ __launch_bounds__(256) void conv5x5_tile_kernel(Conv5x5Args a) {
       }
     }
   }
+}
+
+// ---- filter gradient of the same layer: dw[tap][ci][co] += sum over pixels x[p + tap][ci] * dy[p][co]
+//
+// One image per workgroup tile: its zero-padded input plane and its output gradient sit in LDS, k
+// runs over the 196 pixels (49 MFMA k-steps, no padding), and the 25 x 32 x 64 outputs live in
+// the accumulators of the four waves for the whole kernel (wave = one 16-channel slice of ci x two
+// of co, all 25 taps: 50 tiles, 200 registers), so the pixel loop has no barrier and no LDS
+// writes. Per k-step a wave reads its two dy fragments once and one shifted x fragment per tap:
+// 27 ds_read_b32 feed 50 MFMAs. Pixel strides are = 16 mod 64 banks, so the four pixel groups of
+// a fragment read disjoint banks, also where a row of 14 pixels wraps. Blocks are persistent over
+// images and add their result once, into the gradient copy of their XCD.
+constexpr int kWgPsx = 48;   // x plane pixel stride (32 channels + 16)
+constexpr int kWgPsy = 80;   // dy pixel stride (64 channels + 16)
+constexpr int kWgXFloats = kPW * kPW * kWgPsx;
+constexpr int kWgYFloats = kImgPx * kWgPsy;
+constexpr int kWgXChunks = kImgPx * 8, kWgYChunks = kImgPx * 16;
+constexpr int kWgNpfX = (kWgXChunks + 255) / 256, kWgNpfY = (kWgYChunks + 255) / 256;
+
+__global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(Conv5x5WgradArgs a) {
+  extern __shared__ __align__(16) float lds[];
+  float* sx = lds;
+  float* sy = lds + kWgXFloats;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, n = lane & 15;
+  const int v = wave >> 1, h = wave & 1;   // ci slice 16v.., co slices 32h.. and 32h+16..
+
+  for (int i = tid; i < kWgXFloats / 4; i += 256) reinterpret_cast<float4*>(sx)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  int xdst[kWgNpfX], ydst[kWgNpfY];
+#pragma unroll
+  for (int k = 0; k < kWgNpfX; ++k) {
+    const int c = tid + 256 * k;
+    const int px = (c < kWgXChunks ? c : 0) >> 3, c4 = c & 7;
+    xdst[k] = ((px / kHW + 2) * kPW + px % kHW + 2) * kWgPsx + 4 * c4;
+  }
+#pragma unroll
+  for (int k = 0; k < kWgNpfY; ++k) {
+    const int c = tid + 256 * k;
+    ydst[k] = ((c < kWgYChunks ? c : 0) >> 4) * kWgPsy + 4 * (c & 15);
+  }
+  float4 pfx[kWgNpfX], pfy[kWgNpfY];
+  auto fetch = [&](int img) {
+    const float4* xs = reinterpret_cast<const float4*>(a.x + (size_t)img * kImgPx * 32);
+    const float4* ys = reinterpret_cast<const float4*>(a.dy + (size_t)img * kImgPx * 64);
+#pragma unroll
+    for (int k = 0; k < kWgNpfX; ++k)
+      if (tid + 256 * k < kWgXChunks) pfx[k] = xs[tid + 256 * k];
+#pragma unroll
+    for (int k = 0; k < kWgNpfY; ++k)
+      if (tid + 256 * k < kWgYChunks) pfy[k] = ys[tid + 256 * k];
+  };
+
+  floatx4 acc[25][2];
+#pragma unroll
+  for (int t = 0; t < 25; ++t) acc[t][0] = acc[t][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  int img = blockIdx.x;
+  if (img < a.B) fetch(img);
+  for (; img < a.B; img += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kWgNpfX; ++k)
+      if (tid + 256 * k < kWgXChunks) *reinterpret_cast<float4*>(sx + xdst[k]) = pfx[k];
+#pragma unroll
+    for (int k = 0; k < kWgNpfY; ++k)
+      if (tid + 256 * k < kWgYChunks) *reinterpret_cast<float4*>(sy + ydst[k]) = pfy[k];
+    __syncthreads();
+    if (img + (int)gridDim.x < a.B) fetch(img + gridDim.x);
+
+    // This lane's pixel of k-step ks is 4 ks + g, walked through the rows of 14. The 27 operand
+    // reads of k-step ks + 1 are issued before the 50 MFMAs of k-step ks (two register sets,
+    // the loop body handles two k-steps), so no MFMA waits for LDS.
+    int px_y = 0, px_x = g;
+    auto load_step = [&](float (&av)[25], float (&bv)[2]) {
+      const float* yrow = sy + (px_y * kHW + px_x) * kWgPsy + 32 * h + n;
+      bv[0] = yrow[0];
+      bv[1] = yrow[16];
+      const float* xwin = sx + (px_y * kPW + px_x) * kWgPsx + 16 * v + n;   // window origin of the pixel
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 5; ++kw) av[kh * 5 + kw] = xwin[(kh * kPW + kw) * kWgPsx];
+      px_x += 4;
+      if (px_x >= kHW) { px_x -= kHW; ++px_y; }
+    };
+    auto mfma_step = [&](const float (&av)[25], const float (&bv)[2]) {
+#pragma unroll
+      for (int t = 0; t < 25; ++t) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[0], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[1], acc[t][1], 0, 0, 0);
+      }
+    };
+    constexpr int kSteps = kImgPx / 4;   // 49
+    float a0[25], a1[25], b0[2], b1[2];
+    load_step(a0, b0);
+#pragma unroll 1
+    for (int ks = 0; ks + 2 < kSteps; ks += 2) {
+      load_step(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_step(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma_step(a0, b0);   // k-step 48 (the loop covers 0..47)
+  }
+
+  // lane holds dw[tap][ci = 16v + 4g + i][co = 32h + 16j + n]
+  const int lane_off = (16 * v + 4 * g) * 64 + 32 * h + n;
+  if (a.partials) {
+    float* dst = a.partials + (size_t)blockIdx.x * (25 * 2048) + lane_off;
+#pragma unroll
+    for (int t = 0; t < 25; ++t)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[t * 2048 + i * 64 + 16 * j] = acc[t][j][i];
+    return;
+  }
+  float* dst = a.dw + (a.slot_stride ? (size_t)(blockIdx.x & (kStatSlots - 1)) * a.slot_stride : 0) + lane_off;
+#pragma unroll
+  for (int t = 0; t < 25; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float s = acc[t][j][i];
+        if (s != 0.f) atomicAdd(dst + t * 2048 + i * 64 + 16 * j, s);
+      }
 }
 
 // [25][CIN][COUT] (HWIO filter) -> [25][COUT][CIN]
@@ -212,11 +358,28 @@ void conv5x5_tile(const Conv5x5Args& a, hipStream_t stream) {
     if (!a.bias) throw std::runtime_error("conv5x5_tile: the 32->64 forward form needs a bias");
     // two images per tile halve the padding of the last pixel tile; one image per tile keeps
     // every CU busy at small batches
-    if (a.imgs == 2 || (a.imgs == 0 && a.B >= 1024)) return launch_c5<32, 64, 2, false, true>(a, stream);
+    if (a.imgs == 2 || (a.imgs == 0 && a.B >= 512)) return launch_c5<32, 64, 2, false, true>(a, stream);
     return launch_c5<32, 64, 1, false, true>(a, stream);
   }
   if (a.Cin == 64 && a.Cout == 32 && a.flip) return launch_c5<64, 32, 1, true, false>(a, stream);
   throw std::runtime_error("conv5x5_tile: unsupported channel counts / direction");
+}
+
+int conv5x5_wgrad_parts(int B) {
+  const int cap = 256;   // one workgroup per CU (125 KB of LDS)
+  return ceil_div(B, ceil_div(B, cap));
+}
+
+void conv5x5_wgrad(const Conv5x5WgradArgs& a, hipStream_t stream) {
+  if (a.B < 1) throw std::runtime_error("conv5x5_wgrad: empty batch");
+  const size_t shmem = (size_t)(kWgXFloats + kWgYFloats) * sizeof(float);
+  static const bool once = [&] {
+    ensure_dynamic_lds(reinterpret_cast<const void*>(conv5x5_wgrad_kernel), shmem);
+    return true;
+  }();
+  (void)once;
+  const int grid = conv5x5_wgrad_parts(a.B);
+  launch("conv5x5_wgrad", conv5x5_wgrad_kernel, dim3(grid), dim3(256), shmem, stream, a);
 }
 
 void conv5x5_pack(const Conv5x5PackArgs& a, hipStream_t stream) {

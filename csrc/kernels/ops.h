@@ -127,6 +127,10 @@ void flat_axpy(const AxpyArgs& a, hipStream_t stream);         // y += alpha*x
 // copies, see ConvWgradArgs::dw_slot_stride); the copies are zeroed where they held anything.
 struct SlotReduceArgs { float* y; float* slots; long long n; long long slot_stride; };
 void slot_reduce(const SlotReduceArgs& a, hipStream_t stream);
+// y[0:n] += sum over p < parts of ws[p*stride + (0:n)] (per-workgroup partial results written with
+// plain stores; n and stride multiples of 4).
+struct PartialSumArgs { float* y; const float* ws; long long n; int parts; long long stride; };
+void partial_sum(const PartialSumArgs& a, hipStream_t stream);
 
 struct AddReluArgs { const float* a; const float* b; float* out; long long n; int relu_first; };
 void add_relu_fwd(const AddReluArgs& a, hipStream_t stream);   // relu_first ? relu(a)+b : relu(a+b)

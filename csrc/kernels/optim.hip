@@ -132,7 +132,41 @@ __global__ __launch_bounds__(256) void slot_reduce_kernel(SlotReduceArgs a) {
   }
 }
 
+// One thread per 4 consecutive outputs and per group of kPartGroup partial copies (blockIdx.y), four
+// loads in flight; a single group stores, several groups add atomically (y is an accumulator).
+constexpr int kPartGroup = 32;
+__global__ __launch_bounds__(256) void partial_sum_kernel(PartialSumArgs a) {
+  const long long n4 = a.n >> 2;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  floatx4 s[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) s[u] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const float* src = a.ws + 4 * i;
+  int p = blockIdx.y * kPartGroup;
+  const int p_end = min(a.parts, p + kPartGroup);
+  for (; p + 4 <= p_end; p += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += *reinterpret_cast<const floatx4*>(src + (p + u) * a.stride);
+  }
+  for (; p < p_end; ++p) s[0] += *reinterpret_cast<const floatx4*>(src + p * a.stride);
+  const floatx4 t = (s[0] + s[1]) + (s[2] + s[3]);
+  if (gridDim.y == 1) {
+    floatx4* y4 = reinterpret_cast<floatx4*>(a.y);
+    y4[i] = y4[i] + t;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(a.y + 4 * i + e, t[e]);
+  }
+}
+
 }  // namespace
+
+void partial_sum(const PartialSumArgs& a, hipStream_t stream) {
+  if ((a.n & 3) || (a.stride & 3) || a.parts < 1) throw std::runtime_error("partial_sum: n and stride must be multiples of 4, parts >= 1");
+  launch("partial_sum", partial_sum_kernel, dim3((unsigned)(((a.n >> 2) + 255) / 256), (unsigned)ceil_div(a.parts, kPartGroup)), dim3(256), 0,
+         stream, a);
+}
 
 void slot_reduce(const SlotReduceArgs& a, hipStream_t stream) {
   if ((a.slot_stride & 3) != 0) throw std::runtime_error("slot_reduce: slot stride must be a multiple of 4 floats");

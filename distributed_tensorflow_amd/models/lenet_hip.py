@@ -108,7 +108,10 @@ class LeNetHipStep(StepProgramBase):
                     off, spec = a.offsets[name], a.spec(name)
                     return self._wslots[0, off:off + spec.numel].view(spec.shape)
 
-                nv.conv_wgrad(self.p1, da2, slot_view("conv2_weights"), stride=1, slot_stride=conv_end)
+                # conv2 filter gradient: per-workgroup partial results, one reduction into the arena
+                if not hasattr(self, "_w2_parts"):
+                    self._w2_parts = torch.empty(nv.conv5x5_wgrad_parts(B), 25 * 32 * 64, device=self.device, dtype=torch.float32)
+                nv.conv5x5_wgrad(self.p1, da2, a.grad("conv2_weights"), partials=self._w2_parts)
                 nv.col_sum(da2.view(-1, 64), a.grad("conv2_biases"))
                 # data gradient: the same kernel over the unpacked filter, taps walked backwards
                 nv.conv5x5_tile(da2, a.param("conv2_weights"), flip=True, out=self.dp1)

@@ -332,6 +332,39 @@ def conv5x5_tile(x: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tenso
     return out
 
 
+def conv5x5_wgrad_parts(batch: int) -> int:
+    """Number of per-workgroup partial results conv5x5_wgrad(partials=...) writes for this batch."""
+    return int(hip().conv5x5_wgrad_parts(int(batch)))
+
+
+def conv5x5_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, slot_stride: int = 0,
+                  partials: Optional[torch.Tensor] = None) -> None:
+    """dw [5,5,32,64] += filter gradient of the 5x5 SAME convolution over [B,14,14,32] inputs with
+    output gradient dy [B,14,14,64]; with slot_stride into the per-XCD copies starting at dw.
+    partials [conv5x5_wgrad_parts(B), 51200]: the workgroups store their partial results there
+    without atomics and one partial_sum adds them to dw."""
+    require()
+    b = int(x.shape[0])
+    n = 25 * 32 * 64
+    if tuple(x.shape) != (b, 14, 14, 32) or tuple(dy.shape) != (b, 14, 14, 64) or dw.numel() != n:
+        raise ValueError("conv5x5_wgrad: expected x [B,14,14,32], dy [B,14,14,64], dw [5,5,32,64]")
+    d = dict(x=_chk(x, "x"), dy=_chk(dy, "dy"), dw=_chk(dw, "dw"), slot_stride=slot_stride, B=b)
+    if partials is not None:
+        parts = conv5x5_wgrad_parts(b)
+        if partials.dim() != 2 or partials.shape[0] < parts or partials.shape[1] != n:
+            raise ValueError(f"conv5x5_wgrad: partials must be [>= {parts}, {n}]")
+        d["partials"] = _chk(partials, "partials")
+        d["slot_stride"] = 0
+        hip().conv5x5_wgrad(d, stream())
+        hip().partial_sum(dict(y=_chk(dw, "dw"), ws=_chk(partials, "partials"), n=n, parts=parts, stride=n), stream())
+        return
+    if slot_stride:
+        last = (dw.storage_offset() + (STAT_SLOTS - 1) * slot_stride + dw.numel()) * 4
+        if slot_stride < dw.numel() or last > dw.untyped_storage().nbytes():
+            raise ValueError("conv5x5_wgrad: the slot copies do not fit dw's storage")
+    hip().conv5x5_wgrad(d, stream())
+
+
 def conv_bwd_fused_supported(x: torch.Tensor) -> bool:
     b, h, w_, c = x.shape
     return bool(hip().conv_bwd_fused_supported(b, h, w_, c))

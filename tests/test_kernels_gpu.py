@@ -118,6 +118,25 @@ def test_conv5x5_tile_forward(b, imgs):
 
 
 @pytest.mark.parametrize("b", [1, 5, 300])
+def test_conv5x5_filter_gradient(b):
+    x = rnd(b, 14, 14, 32)
+    dy = rnd(b, 14, 14, 64)
+    wt = rnd(5, 5, 32, 64, scale=0.05).requires_grad_(True)
+    ref.conv2d_same(x, wt, 1).backward(dy)
+    slots = torch.zeros(nv.STAT_SLOTS, 25 * 32 * 64 + 256, device=DEV)
+    nv.conv5x5_wgrad(x, dy, slots[0, :25 * 32 * 64].view(5, 5, 32, 64), slot_stride=slots.shape[1])
+    close(slots.sum(0)[:25 * 32 * 64].view(5, 5, 32, 64), wt.grad, tol=5e-4)
+    dw = torch.zeros(5, 5, 32, 64, device=DEV)
+    nv.conv5x5_wgrad(x, dy, dw)
+    close(dw, wt.grad, tol=5e-4)
+    # per-workgroup partial results (no atomics) summed by one reduction; the buffer starts dirty
+    ws = torch.full((nv.conv5x5_wgrad_parts(b), 25 * 32 * 64), 7.0, device=DEV)
+    dw2 = torch.ones(5, 5, 32, 64, device=DEV)
+    nv.conv5x5_wgrad(x, dy, dw2, partials=ws)
+    close(dw2 - 1.0, wt.grad, tol=5e-4)
+
+
+@pytest.mark.parametrize("b", [1, 5, 300])
 def test_conv5x5_tile_data_gradient(b):
     dy = rnd(b, 14, 14, 64)
     wt = rnd(5, 5, 32, 64, scale=0.05)
