@@ -64,7 +64,7 @@ struct BF {
   static constexpr int LDS_FLOATS = (TILE_FLOATS > RED_FLOATS ? TILE_FLOATS : RED_FLOATS) + W_FLOATS + 6 * XC + 3 * C;
   static_assert(PPW == 1, "one (ci, co) tile pair per wave");
   static_assert((TH * TW) % 16 == 0 && N_MT % (4 * MTW) == 0 && (STEPS / WX) % 2 == 0, "band must split evenly");
-  static_assert(TW % 4 == 0, "the four pixels of a k-step must share a row");
+  static_assert(TW % 8 == 0 && (TH * TW) % 16 == 0, "k-steps are taken from 16-pixel segments of whole rows");
 };
 
 template <int C, int NT, int TW, int TH, bool DYBN>
@@ -257,9 +257,13 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
   // filter gradient: this wave's (ci tile, co tile) pair and pixel split
   const int wp = wave % WP, wx = wave / WP;
   const int ci_t = wp / CO_T, co_t = wp % CO_T;
-  const int laneA = q * XPP + ci_t * 16 + l15;                // x[pixel q of the step][ci]
+  // The four pixels of k-step (seg, j) are 16 seg + j + 4 q' (q' = lane group), not four neighbours:
+  // pixel strides are C + 4 = 4 mod 16 floats, so pixels 4 apart start 16 banks apart and the 64
+  // lanes of a fragment read (4 pixels x 16 channels) touch 64 different banks.
+  const int dq = 4 * q;
+  const int laneA = dq * XPP + ci_t * 16 + l15;               // x[pixel][ci]
   // dy[pixel - (tap - 1)]: halo pixel (r + 2 - kh, c + 2 - kw)
-  const int laneB = q * CPP + co_t * 16 + l15;
+  const int laneB = ((dq / TW) * LW + dq % TW) * CPP + co_t * 16 + l15;
   const float w_sc = s_co[ci_t * 16 + l15], w_sh = s_co[XC + ci_t * 16 + l15];
 
   floatx4 accw[9];
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
   for (int j = 0; j < NT; ++j) { st1[j] = floatx4{0.f, 0.f, 0.f, 0.f}; st2[j] = floatx4{0.f, 0.f, 0.f, 0.f}; }
 
   auto read_wfrags = [&](int step, float& af, float (&bf)[9]) {
-    const int p = step * 4;
+    const int p = (step >> 2) * 16 + (step & 3);   // pixel of lane group 0
     const int row = p / TW, col = p % TW;
     af = s_x[p * XPP + laneA];
     const float* bp = s_dy + ((row + 2) * LW + col + 2) * CPP + laneB;
