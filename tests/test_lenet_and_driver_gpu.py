@@ -98,7 +98,7 @@ def _gpu_sync_worker(rank, world, board_name, mode):
 
     from distributed_tensorflow_amd.parallel import control_plane
     from distributed_tensorflow_amd.parallel.comm import Communicator
-    from distributed_tensorflow_amd.parallel.strategies import Backup, FullSync
+    from distributed_tensorflow_amd.parallel.strategies import Backup, FullSync, Interval, SoftKill, Weighted
     from distributed_tensorflow_amd.train.replica import HipReplica
 
     os.environ["LOCAL_RANK"] = "0"
@@ -112,25 +112,39 @@ def _gpu_sync_worker(rank, world, board_name, mode):
         comm.enable_p2p(rep.arena.grads_full.numel(), blocks=8)
     if mode == "backup":
         strat = Backup(comm, board, world - 1)
+    elif mode == "interval":
+        strat = Interval(comm, board, 60000.0)      # generous window: every gradient is in time
+    elif mode == "interval_tight":
+        strat = Interval(comm, board, 0.001)        # 1 us window: every backward pass is cut short, no update
+    elif mode == "soft_kill":
+        strat = SoftKill(comm, board, 1)            # the first arrival stops the other replica's backward pass
+    elif mode == "weighted":
+        strat = Weighted(comm, board, 1, 142)       # one simulated kill per step
     else:
         strat = FullSync(comm, board, reduce_scatter=(mode == "sharded"))
     losses = []
+    applied = 0
     for it in range(6):
         res = strat.step(rep, it, 1e-3)
+        applied += int(res.applied)
         losses.append(rep.loss_value())
     rep.synchronize()
     psum = rep.arena.params.double().sum().item()
     comm.barrier()
     comm.close()
-    return dict(losses=losses, psum=psum, updates=rep.updates_applied)
+    return dict(losses=losses, psum=psum, updates=rep.updates_applied, applied=applied)
 
 
-@pytest.mark.parametrize("mode", ["sync", "backup", "sharded", "p2p"])
+@pytest.mark.parametrize("mode", ["sync", "backup", "sharded", "p2p", "interval", "interval_tight", "soft_kill", "weighted"])
 def test_two_gpu_replicas_stay_identical(mode):
     out = run_workers(_gpu_sync_worker, 2, f"dtf_g_{mode}_{os.getpid()}", mode, timeout=300)
     assert abs(out[0]["psum"] - out[1]["psum"]) < 1e-6 * max(1.0, abs(out[0]["psum"]))
+    if mode == "interval_tight":
+        # nothing arrives inside a 1 us window: no update is ever applied, on either replica
+        assert all(o["updates"] == 0 and o["applied"] == 0 for o in out)
+        return
     assert all(o["updates"] == 6 for o in out)
-    if mode == "backup":
+    if mode in ("backup", "soft_kill", "weighted"):
         # the update may come from the OTHER replica's batch only, so a replica's own loss need not fall
         assert all(l == l and l < 10 for o in out for l in o["losses"])
     else:
