@@ -22,10 +22,9 @@ from __future__ import annotations
 import os
 import time
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Tuple
+from typing import List, Tuple
 
 import torch
-import torch.distributed as dist
 
 from ..ops import reference as ref
 from .comm import Communicator

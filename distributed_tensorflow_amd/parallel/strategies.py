@@ -30,10 +30,9 @@ from __future__ import annotations
 
 import time
 from dataclasses import dataclass
-from typing import List, Optional
+from typing import List
 
 import numpy as np
-import torch
 
 from .comm import Communicator
 

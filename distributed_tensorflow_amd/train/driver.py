@@ -20,8 +20,6 @@ import time
 from datetime import datetime
 from typing import Dict, Optional
 
-import numpy as np
-import torch
 
 from .. import lr as lr_mod
 from ..checkpoint.saver import Saver

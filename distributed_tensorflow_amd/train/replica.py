@@ -15,7 +15,6 @@ synchronisation strategies:
 from __future__ import annotations
 
 import contextlib
-import time
 from typing import Callable, List, Optional, Tuple
 
 import torch

@@ -9,7 +9,6 @@ import sys
 import threading
 import time
 
-import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

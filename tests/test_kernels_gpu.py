@@ -4,7 +4,6 @@ Operands are asymmetric random tensors (a swapped row/column map in an MFMA epil
 symmetric data), shapes include non-multiples of the tile sizes, and every test runs the
 native extension (native.require() raises if it is missing).
 """
-import math
 
 import pytest
 import torch

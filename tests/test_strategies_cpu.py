@@ -4,7 +4,6 @@ import os
 import time
 
 import numpy as np
-import pytest
 import torch
 
 from mp_util import run_workers

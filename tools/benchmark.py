@@ -12,7 +12,6 @@ time CDF plus the percentile report.
 """
 from __future__ import annotations
 
-import glob
 import json
 import os
 import re
