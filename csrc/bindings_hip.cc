@@ -102,6 +102,7 @@ PYBIND11_MODULE(_hip, m) {
     Conv5x5Args a{};
     P(x, const float); P(w, const float); P(bias, const float); P(y, float);
     V(B); V(Cin); V(Cout); V(flip); V(imgs);
+    P(pool_dp, const float); P(pool_arg, const unsigned char); P(pool_p, const float);
     conv5x5_tile(a, as_stream(stream));
   });
   m.def("conv5x5_pack", [](const py::dict& d, uint64_t stream) {
@@ -113,6 +114,7 @@ PYBIND11_MODULE(_hip, m) {
   m.def("conv5x5_wgrad", [](const py::dict& d, uint64_t stream) {
     Conv5x5WgradArgs a{};
     P(x, const float); P(dy, const float); P(dw, float); V(slot_stride); V(B); P(partials, float);
+    P(pool_dp, const float); P(pool_arg, const unsigned char); P(pool_p, const float);
     conv5x5_wgrad(a, as_stream(stream));
   });
   m.def("conv5x5_wgrad_parts", &conv5x5_wgrad_parts);

@@ -146,6 +146,12 @@ struct Conv5x5Args {
   int B, Cin, Cout;
   int flip;
   int imgs;           // images per workgroup tile: 0 = choose by batch, 1 or 2 (forward form)
+  // Data-gradient form only, instead of x: the gradient dp [B,7,7,64] at the 2x2 max pool that
+  // follows the convolution, the pool's winner positions and its (ReLU) maxima; the kernel stages
+  // the pool + ReLU backward of dp on the fly.
+  const float* pool_dp;
+  const unsigned char* pool_arg;
+  const float* pool_p;
 };
 struct Conv5x5PackArgs {
   const float* w;   // [25][Cin][Cout]
@@ -160,6 +166,10 @@ struct Conv5x5WgradArgs {
   float* dw;
   int slot_stride;
   int B;
+  // Instead of dy (see Conv5x5Args): pooled gradient, winner positions, pooled maxima.
+  const float* pool_dp;
+  const unsigned char* pool_arg;
+  const float* pool_p;
   // Non-null: workgroup b stores its whole partial result at partials + b * 25*32*64 with plain
   // stores instead of adding it to dw (no atomics; sum the conv5x5_wgrad_parts(B) copies with
   // partial_sum). Every element is written, so the buffer needs no clearing.

@@ -25,6 +25,34 @@ constexpr int kHW = 14;            // feature-map height and width
 constexpr int kPW = kHW + 4;       // padded plane (halo 2 on every side)
 constexpr int kImgPx = kHW * kHW;  // 196
 
+// The 64-channel gradient at the second convolution's output is the max-pool backward of the
+// gradient dp at the pooled tensor: dy[y][x][c] = dp[y/2][x/2][c] if (y, x) is the window's winner
+// (arg, encoded as in maxpool2x2_fwd) and the pooled maximum p is positive (ReLU), else 0. With
+// `pool_dp` set, the kernels below stage dy from (dp, arg, p) directly, one 16-byte chunk of a
+// pooled cell feeding its four pixels, so the full-resolution gradient is never written.
+constexpr int kCells = 49;                 // 7 x 7 pooled cells per image
+constexpr int kCellChunks = kCells * 16;   // 16-byte chunks (4 of 64 channels) per image
+constexpr int kNpc = (kCellChunks + 255) / 256;
+struct PooledChunk {
+  float4 dp, p;
+  unsigned arg;
+};
+__device__ __forceinline__ void pooled_fetch(const float* dp, const unsigned char* arg, const float* p, int img, int cc, PooledChunk& o) {
+  const size_t off = ((size_t)img * kCells + (cc >> 4)) * 64 + 4 * (cc & 15);
+  o.dp = *reinterpret_cast<const float4*>(dp + off);
+  o.p = *reinterpret_cast<const float4*>(p + off);
+  o.arg = *reinterpret_cast<const unsigned*>(arg + off);
+}
+// value of window position pos (0..3) for the chunk
+__device__ __forceinline__ float4 pooled_value(const PooledChunk& c, unsigned pos) {
+  float4 v;
+  v.x = ((c.arg & 0xffu) == pos && c.p.x > 0.f) ? c.dp.x : 0.f;
+  v.y = (((c.arg >> 8) & 0xffu) == pos && c.p.y > 0.f) ? c.dp.y : 0.f;
+  v.z = (((c.arg >> 16) & 0xffu) == pos && c.p.z > 0.f) ? c.dp.z : 0.f;
+  v.w = ((c.arg >> 24) == pos && c.p.w > 0.f) ? c.dp.w : 0.f;
+  return v;
+}
+
 template <int CIN, int COUT, int IMGS>
 struct C5 {
   static constexpr int PS = CIN + 4;                 // LDS pixel stride (floats)
@@ -43,9 +71,10 @@ struct C5 {
 };
 
 // x [B,14,14,CIN]; w [25][COUT][CIN] (FLIP: tap t reads w[24-t]); y [B,14,14,COUT].
-template <int CIN, int COUT, int IMGS, bool FLIP, bool BIAS_RELU>
+template <int CIN, int COUT, int IMGS, bool FLIP, bool BIAS_RELU, bool POOLED>
 __global__ __launch_bounds__(256) void conv5x5_tile_kernel(Conv5x5Args a) {
   using G = C5<CIN, COUT, IMGS>;
+  static_assert(!POOLED || (CIN == 64 && IMGS == 1), "pooled staging is the data-gradient form");
   extern __shared__ __align__(16) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,14 +105,30 @@ __global__ __launch_bounds__(256) void conv5x5_tile_kernel(Conv5x5Args a) {
     const int img = px / kImgPx, r = px % kImgPx;
     sdst[k] = ((img * kPW + r / kHW + 2) * kPW + r % kHW + 2) * G::PS + 4 * c4;
   }
-  float4 pf[G::NPF];
-  auto fetch = [&](int tile) {
-    const int valid = min(G::PX, (a.B - tile * IMGS) * kImgPx) * G::C4;
-    const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)tile * G::PX * CIN);
+  float4 pf[POOLED ? 1 : G::NPF];
+  PooledChunk pc[POOLED ? kNpc : 1];
+  int pdst[POOLED ? kNpc : 1];
+  if constexpr (POOLED) {
 #pragma unroll
-    for (int k = 0; k < G::NPF; ++k) {
-      const int c = tid + 256 * k;
-      pf[k] = c < valid ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < kNpc; ++k) {
+      const int cc = min(tid + 256 * k, kCellChunks - 1);
+      const int cell = cc >> 4;
+      pdst[k] = ((2 * (cell / 7) + 2) * kPW + 2 * (cell % 7) + 2) * G::PS + 4 * (cc & 15);
+    }
+  }
+  auto fetch = [&](int tile) {
+    if constexpr (POOLED) {
+#pragma unroll
+      for (int k = 0; k < kNpc; ++k)
+        if (tid + 256 * k < kCellChunks) pooled_fetch(a.pool_dp, a.pool_arg, a.pool_p, tile, tid + 256 * k, pc[k]);
+    } else {
+      const int valid = min(G::PX, (a.B - tile * IMGS) * kImgPx) * G::C4;
+      const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)tile * G::PX * CIN);
+#pragma unroll
+      for (int k = 0; k < G::NPF; ++k) {
+        const int c = tid + 256 * k;
+        pf[k] = c < valid ? src[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   };
 
@@ -100,9 +145,21 @@ __global__ __launch_bounds__(256) void conv5x5_tile_kernel(Conv5x5Args a) {
   if (tile < n_tiles) fetch(tile);
   for (; tile < n_tiles; tile += gridDim.x) {
     __syncthreads();   // every wave is done reading the previous tile (and the zero fill landed)
+    if constexpr (POOLED) {
 #pragma unroll
-    for (int k = 0; k < G::NPF; ++k)
-      if (tid + 256 * k < G::CHUNKS) *reinterpret_cast<float4*>(lds + sdst[k]) = pf[k];
+      for (int k = 0; k < kNpc; ++k)
+        if (tid + 256 * k < kCellChunks) {
+          float* d = lds + pdst[k];
+          *reinterpret_cast<float4*>(d) = pooled_value(pc[k], 0);
+          *reinterpret_cast<float4*>(d + G::PS) = pooled_value(pc[k], 1);
+          *reinterpret_cast<float4*>(d + kPW * G::PS) = pooled_value(pc[k], 2);
+          *reinterpret_cast<float4*>(d + (kPW + 1) * G::PS) = pooled_value(pc[k], 3);
+        }
+    } else {
+#pragma unroll
+      for (int k = 0; k < G::NPF; ++k)
+        if (tid + 256 * k < G::CHUNKS) *reinterpret_cast<float4*>(lds + sdst[k]) = pf[k];
+    }
     __syncthreads();
     if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
 
@@ -202,6 +259,7 @@ constexpr int kWgYFloats = kImgPx * kWgPsy;
 constexpr int kWgXChunks = kImgPx * 8, kWgYChunks = kImgPx * 16;
 constexpr int kWgNpfX = (kWgXChunks + 255) / 256, kWgNpfY = (kWgYChunks + 255) / 256;
 
+template <bool POOLED>
 __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(Conv5x5WgradArgs a) {
   extern __shared__ __align__(16) float lds[];
   float* sx = lds;
@@ -225,16 +283,32 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(Conv5x5WgradArgs a) 
     const int c = tid + 256 * k;
     ydst[k] = ((c < kWgYChunks ? c : 0) >> 4) * kWgPsy + 4 * (c & 15);
   }
-  float4 pfx[kWgNpfX], pfy[kWgNpfY];
+  float4 pfx[kWgNpfX], pfy[POOLED ? 1 : kWgNpfY];
+  PooledChunk pc[POOLED ? kNpc : 1];
+  int pdst[POOLED ? kNpc : 1];
+  if constexpr (POOLED) {
+#pragma unroll
+    for (int k = 0; k < kNpc; ++k) {
+      const int cc = min(tid + 256 * k, kCellChunks - 1);
+      const int cell = cc >> 4;
+      pdst[k] = (2 * (cell / 7) * kHW + 2 * (cell % 7)) * kWgPsy + 4 * (cc & 15);
+    }
+  }
   auto fetch = [&](int img) {
     const float4* xs = reinterpret_cast<const float4*>(a.x + (size_t)img * kImgPx * 32);
-    const float4* ys = reinterpret_cast<const float4*>(a.dy + (size_t)img * kImgPx * 64);
 #pragma unroll
     for (int k = 0; k < kWgNpfX; ++k)
       if (tid + 256 * k < kWgXChunks) pfx[k] = xs[tid + 256 * k];
+    if constexpr (POOLED) {
 #pragma unroll
-    for (int k = 0; k < kWgNpfY; ++k)
-      if (tid + 256 * k < kWgYChunks) pfy[k] = ys[tid + 256 * k];
+      for (int k = 0; k < kNpc; ++k)
+        if (tid + 256 * k < kCellChunks) pooled_fetch(a.pool_dp, a.pool_arg, a.pool_p, img, tid + 256 * k, pc[k]);
+    } else {
+      const float4* ys = reinterpret_cast<const float4*>(a.dy + (size_t)img * kImgPx * 64);
+#pragma unroll
+      for (int k = 0; k < kWgNpfY; ++k)
+        if (tid + 256 * k < kWgYChunks) pfy[k] = ys[tid + 256 * k];
+    }
   };
 
   floatx4 acc[25][2];
@@ -248,9 +322,21 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(Conv5x5WgradArgs a) 
 #pragma unroll
     for (int k = 0; k < kWgNpfX; ++k)
       if (tid + 256 * k < kWgXChunks) *reinterpret_cast<float4*>(sx + xdst[k]) = pfx[k];
+    if constexpr (POOLED) {
 #pragma unroll
-    for (int k = 0; k < kWgNpfY; ++k)
-      if (tid + 256 * k < kWgYChunks) *reinterpret_cast<float4*>(sy + ydst[k]) = pfy[k];
+      for (int k = 0; k < kNpc; ++k)
+        if (tid + 256 * k < kCellChunks) {
+          float* d = sy + pdst[k];
+          *reinterpret_cast<float4*>(d) = pooled_value(pc[k], 0);
+          *reinterpret_cast<float4*>(d + kWgPsy) = pooled_value(pc[k], 1);
+          *reinterpret_cast<float4*>(d + kHW * kWgPsy) = pooled_value(pc[k], 2);
+          *reinterpret_cast<float4*>(d + (kHW + 1) * kWgPsy) = pooled_value(pc[k], 3);
+        }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kWgNpfY; ++k)
+        if (tid + 256 * k < kWgYChunks) *reinterpret_cast<float4*>(sy + ydst[k]) = pfy[k];
+    }
     __syncthreads();
     if (img + (int)gridDim.x < a.B) fetch(img + gridDim.x);
 
@@ -328,10 +414,10 @@ __global__ __launch_bounds__(256) void conv5x5_pack_kernel(Conv5x5PackArgs a) {
   a.out[i] = a.w[(size_t)tap * per_tap + ci * a.Cout + co];
 }
 
-template <int CIN, int COUT, int IMGS, bool FLIP, bool BIAS_RELU>
+template <int CIN, int COUT, int IMGS, bool FLIP, bool BIAS_RELU, bool POOLED = false>
 void launch_c5(const Conv5x5Args& a, hipStream_t stream) {
   using G = C5<CIN, COUT, IMGS>;
-  auto kernel = conv5x5_tile_kernel<CIN, COUT, IMGS, FLIP, BIAS_RELU>;
+  auto kernel = conv5x5_tile_kernel<CIN, COUT, IMGS, FLIP, BIAS_RELU, POOLED>;
   const size_t shmem = (size_t)G::LDS_FLOATS * sizeof(float);
   static const int bpc = [&] {
     ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), shmem);
@@ -361,7 +447,14 @@ void conv5x5_tile(const Conv5x5Args& a, hipStream_t stream) {
     if (a.imgs == 2 || (a.imgs == 0 && a.B >= 512)) return launch_c5<32, 64, 2, false, true>(a, stream);
     return launch_c5<32, 64, 1, false, true>(a, stream);
   }
-  if (a.Cin == 64 && a.Cout == 32 && a.flip) return launch_c5<64, 32, 1, true, false>(a, stream);
+  if (a.Cin == 64 && a.Cout == 32 && a.flip) {
+    if (a.pool_dp) {
+      if (!a.pool_arg || !a.pool_p) throw std::runtime_error("conv5x5_tile: pooled staging needs dp, arg and p");
+      return launch_c5<64, 32, 1, true, false, true>(a, stream);
+    }
+    if (!a.x) throw std::runtime_error("conv5x5_tile: null input");
+    return launch_c5<64, 32, 1, true, false>(a, stream);
+  }
   throw std::runtime_error("conv5x5_tile: unsupported channel counts / direction");
 }
 
@@ -374,12 +467,19 @@ void conv5x5_wgrad(const Conv5x5WgradArgs& a, hipStream_t stream) {
   if (a.B < 1) throw std::runtime_error("conv5x5_wgrad: empty batch");
   const size_t shmem = (size_t)(kWgXFloats + kWgYFloats) * sizeof(float);
   static const bool once = [&] {
-    ensure_dynamic_lds(reinterpret_cast<const void*>(conv5x5_wgrad_kernel), shmem);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(conv5x5_wgrad_kernel<false>), shmem);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(conv5x5_wgrad_kernel<true>), shmem);
     return true;
   }();
   (void)once;
   const int grid = conv5x5_wgrad_parts(a.B);
-  launch("conv5x5_wgrad", conv5x5_wgrad_kernel, dim3(grid), dim3(256), shmem, stream, a);
+  if (a.pool_dp) {
+    if (!a.pool_arg || !a.pool_p) throw std::runtime_error("conv5x5_wgrad: pooled staging needs dp, arg and p");
+    launch("conv5x5_wgrad", conv5x5_wgrad_kernel<true>, dim3(grid), dim3(256), shmem, stream, a);
+  } else {
+    if (!a.dy) throw std::runtime_error("conv5x5_wgrad: null output gradient");
+    launch("conv5x5_wgrad", conv5x5_wgrad_kernel<false>, dim3(grid), dim3(256), shmem, stream, a);
+  }
 }
 
 void conv5x5_pack(const Conv5x5PackArgs& a, hipStream_t stream) {

@@ -97,8 +97,12 @@ class LeNetHipStep(StepProgramBase):
                 else:
                     lo = a.total
                 nv.gemm(self.dh, a.param("fc1_weights"), trans_b=True, out=self.dp2)
-                da2 = nv.maxpool2x2_bwd(self.dp2.view(B, 7, 7, 64), self.arg2, self.p2, (B, 14, 14, 64), relu_mask=True)
-                self.da2 = da2
+                # The gradient at conv2's output is the pool + ReLU backward of dp2; both conv2 backward
+                # kernels form it while staging, so it is never written. Its per-channel sum (the bias
+                # gradient) is the sum of dp2 over the cells whose maximum survived the ReLU.
+                dp2 = self.dp2.view(B, 7, 7, 64)
+                nv.relu_bwd(dp2, self.p2, out=dp2)
+                pooled2 = (dp2, self.arg2, self.p2)
                 # filter gradients accumulate in per-XCD copies of the conv part of the arena
                 conv_end = a.offsets["fc1_weights"]
                 if not hasattr(self, "_wslots"):
@@ -111,10 +115,10 @@ class LeNetHipStep(StepProgramBase):
                 # conv2 filter gradient: per-workgroup partial results, one reduction into the arena
                 if not hasattr(self, "_w2_parts"):
                     self._w2_parts = torch.empty(nv.conv5x5_wgrad_parts(B), 25 * 32 * 64, device=self.device, dtype=torch.float32)
-                nv.conv5x5_wgrad(self.p1, da2, a.grad("conv2_weights"), partials=self._w2_parts)
-                nv.col_sum(da2.view(-1, 64), a.grad("conv2_biases"))
+                nv.conv5x5_wgrad(self.p1, None, a.grad("conv2_weights"), partials=self._w2_parts, pooled=pooled2)
+                nv.col_sum(dp2.view(-1, 64), a.grad("conv2_biases"))
                 # data gradient: the same kernel over the unpacked filter, taps walked backwards
-                nv.conv5x5_tile(da2, a.param("conv2_weights"), flip=True, out=self.dp1)
+                nv.conv5x5_tile(None, a.param("conv2_weights"), flip=True, out=self.dp1, pooled=pooled2)
                 # pool backward + ReLU mask + filter and bias gradients of conv1 in one kernel
                 nv.conv1_pool_bwd(self.images, self.dp1, self.arg1, self.p1, slot_view("conv1_weights"),
                                   slot_view("conv1_biases"), slot_stride=conv_end)

@@ -304,26 +304,47 @@ def conv5x5_pack(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
     return out
 
 
-def conv5x5_tile(x: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = None, flip: bool = False,
-                 out: Optional[torch.Tensor] = None, imgs: int = 0) -> torch.Tensor:
+def _pooled_operands(pooled, b: int, who: str) -> dict:
+    dp, arg, pm = pooled
+    shp = (b, 7, 7, 64)
+    if tuple(dp.shape) != shp or tuple(arg.shape) != shp or tuple(pm.shape) != shp:
+        raise ValueError(f"{who}: pooled = (dp, arg, p), each [B,7,7,64]")
+    return dict(pool_dp=_chk(dp, "pool_dp"), pool_arg=_chk(arg, "pool_arg", torch.uint8), pool_p=_chk(pm, "pool_p"))
+
+
+def conv5x5_tile(x: Optional[torch.Tensor], w: torch.Tensor, *, bias: Optional[torch.Tensor] = None, flip: bool = False,
+                 out: Optional[torch.Tensor] = None, imgs: int = 0, pooled=None) -> torch.Tensor:
     """5x5 stride-1 SAME convolution over [B,14,14,C] maps with whole images per workgroup.
     flip=False: x has 32 channels, w = conv5x5_pack(filter), returns relu(conv + bias) with 64
     channels. flip=True: x is the 64-channel output gradient, w = the [5,5,32,64] filter itself,
-    returns the 32-channel input gradient (see csrc/kernels/conv.h: Conv5x5Args)."""
+    returns the 32-channel input gradient (see csrc/kernels/conv.h: Conv5x5Args). With
+    pooled=(dp, arg, p) (flip only, x=None) the output gradient is the 2x2 max-pool + ReLU backward
+    of dp [B,7,7,64], formed while staging instead of being read from memory."""
     require()
-    if x.dim() != 4 or x.shape[1] != 14 or x.shape[2] != 14:
-        raise ValueError("conv5x5_tile: expected [B,14,14,C] input")
-    b, cin = int(x.shape[0]), int(x.shape[3])
+    if pooled is not None:
+        if not flip or x is not None:
+            raise ValueError("conv5x5_tile: pooled staging replaces x in the flip form")
+        b, cin = int(pooled[0].shape[0]), 64
+        dev = pooled[0].device
+    else:
+        if x.dim() != 4 or x.shape[1] != 14 or x.shape[2] != 14:
+            raise ValueError("conv5x5_tile: expected [B,14,14,C] input")
+        b, cin = int(x.shape[0]), int(x.shape[3])
+        dev = x.device
     cout = 32 if flip else 64
     if cin != (64 if flip else 32) or w.numel() != 25 * 32 * 64:
         raise ValueError("conv5x5_tile: channel counts must be 32->64 (forward) or 64->32 (flip)")
     if imgs not in (0, 1, 2):
         raise ValueError("conv5x5_tile: imgs must be 0, 1 or 2")
     if out is None:
-        out = torch.empty((b, 14, 14, cout), device=x.device, dtype=torch.float32)
+        out = torch.empty((b, 14, 14, cout), device=dev, dtype=torch.float32)
     elif tuple(out.shape) != (b, 14, 14, cout):
         raise ValueError("conv5x5_tile: out has the wrong shape")
-    d = dict(x=_chk(x, "x"), w=_chk(w, "w"), y=_chk(out, "y"), B=b, Cin=cin, Cout=cout, flip=int(flip), imgs=imgs)
+    d = dict(w=_chk(w, "w"), y=_chk(out, "y"), B=b, Cin=cin, Cout=cout, flip=int(flip), imgs=imgs)
+    if pooled is not None:
+        d.update(_pooled_operands(pooled, b, "conv5x5_tile"))
+    else:
+        d["x"] = _chk(x, "x")
     if not flip:
         if bias is None or bias.numel() != cout:
             raise ValueError("conv5x5_tile: the forward form needs a bias of Cout elements")
@@ -337,18 +358,27 @@ def conv5x5_wgrad_parts(batch: int) -> int:
     return int(hip().conv5x5_wgrad_parts(int(batch)))
 
 
-def conv5x5_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, slot_stride: int = 0,
-                  partials: Optional[torch.Tensor] = None) -> None:
+def conv5x5_wgrad(x: torch.Tensor, dy: Optional[torch.Tensor], dw: torch.Tensor, slot_stride: int = 0,
+                  partials: Optional[torch.Tensor] = None, pooled=None) -> None:
     """dw [5,5,32,64] += filter gradient of the 5x5 SAME convolution over [B,14,14,32] inputs with
     output gradient dy [B,14,14,64]; with slot_stride into the per-XCD copies starting at dw.
     partials [conv5x5_wgrad_parts(B), 51200]: the workgroups store their partial results there
-    without atomics and one partial_sum adds them to dw."""
+    without atomics and one partial_sum adds them to dw. pooled=(dp, arg, p) with dy=None: the
+    output gradient is the max-pool + ReLU backward of dp [B,7,7,64], formed while staging."""
     require()
     b = int(x.shape[0])
     n = 25 * 32 * 64
-    if tuple(x.shape) != (b, 14, 14, 32) or tuple(dy.shape) != (b, 14, 14, 64) or dw.numel() != n:
-        raise ValueError("conv5x5_wgrad: expected x [B,14,14,32], dy [B,14,14,64], dw [5,5,32,64]")
-    d = dict(x=_chk(x, "x"), dy=_chk(dy, "dy"), dw=_chk(dw, "dw"), slot_stride=slot_stride, B=b)
+    if tuple(x.shape) != (b, 14, 14, 32) or dw.numel() != n:
+        raise ValueError("conv5x5_wgrad: expected x [B,14,14,32], dw [5,5,32,64]")
+    d = dict(x=_chk(x, "x"), dw=_chk(dw, "dw"), slot_stride=slot_stride, B=b)
+    if pooled is not None:
+        if dy is not None:
+            raise ValueError("conv5x5_wgrad: pass either dy or pooled")
+        d.update(_pooled_operands(pooled, b, "conv5x5_wgrad"))
+    else:
+        if tuple(dy.shape) != (b, 14, 14, 64):
+            raise ValueError("conv5x5_wgrad: expected dy [B,14,14,64]")
+        d["dy"] = _chk(dy, "dy")
     if partials is not None:
         parts = conv5x5_wgrad_parts(b)
         if partials.dim() != 2 or partials.shape[0] < parts or partials.shape[1] != n:

@@ -135,6 +135,28 @@ def test_conv5x5_filter_gradient(b):
     close(dw2 - 1.0, wt.grad, tol=5e-4)
 
 
+@pytest.mark.parametrize("b", [1, 6, 270])
+def test_conv5x5_backward_from_the_pooled_gradient(b):
+    """Data and filter gradient of the second LeNet convolution computed straight from the
+    gradient at the max pool (pool + ReLU backward formed while staging) equal the unfused chain."""
+    x = rnd(b, 14, 14, 32)
+    wt = rnd(5, 5, 32, 64, scale=0.05)
+    bias = rnd(64, scale=0.3)
+    act = nv.conv5x5_tile(x, nv.conv5x5_pack(wt), bias=bias)
+    pooled, arg = nv.maxpool2x2_fwd(act)
+    dp = rnd(b, 7, 7, 64)
+    dy = nv.maxpool2x2_bwd(dp, arg, pooled, (b, 14, 14, 64), relu_mask=True)
+    want_dx = nv.conv5x5_tile(dy, wt, flip=True)
+    got_dx = nv.conv5x5_tile(None, wt, flip=True, pooled=(dp, arg, pooled))
+    close(got_dx, want_dx, tol=1e-6)
+    want_dw = torch.zeros(5, 5, 32, 64, device=DEV)
+    nv.conv5x5_wgrad(x, dy, want_dw)
+    ws = torch.empty(nv.conv5x5_wgrad_parts(b), 25 * 32 * 64, device=DEV)
+    got_dw = torch.zeros(5, 5, 32, 64, device=DEV)
+    nv.conv5x5_wgrad(x, None, got_dw, partials=ws, pooled=(dp, arg, pooled))
+    close(got_dw, want_dw, tol=1e-5)
+
+
 @pytest.mark.parametrize("b", [1, 5, 300])
 def test_conv5x5_tile_data_gradient(b):
     dy = rnd(b, 14, 14, 64)
