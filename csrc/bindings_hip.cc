@@ -103,6 +103,7 @@ PYBIND11_MODULE(_hip, m) {
     P(x, const float); P(w, const float); P(bias, const float); P(y, float);
     V(B); V(Cin); V(Cout); V(flip); V(imgs);
     P(pool_dp, const float); P(pool_arg, const unsigned char); P(pool_p, const float);
+    P(pool_out, float); P(pool_arg_out, unsigned char);
     conv5x5_tile(a, as_stream(stream));
   });
   m.def("conv5x5_pack", [](const py::dict& d, uint64_t stream) {

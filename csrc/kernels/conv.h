@@ -152,6 +152,10 @@ struct Conv5x5Args {
   const float* pool_dp;
   const unsigned char* pool_arg;
   const float* pool_p;
+  // Forward form only, instead of y: the 2x2 / 2 max pool of the activation, [B,7,7,64] maxima and
+  // winner positions (maxpool2x2_fwd's encoding); the activation itself is not written.
+  float* pool_out;
+  unsigned char* pool_arg_out;
 };
 struct Conv5x5PackArgs {
   const float* w;   // [25][Cin][Cout]

@@ -65,16 +65,20 @@ struct C5 {
   static constexpr int C4 = CIN / 4;
   static constexpr int CHUNKS = PX * C4;             // 16-byte chunks of a tile's input
   static constexpr int NPF = (CHUNKS + 255) / 256;
-  static constexpr int LDS_FLOATS = IMGS * kPW * kPW * PS;
+  static constexpr int LDS_PLANE_FLOATS = IMGS * kPW * kPW * PS;
+  static constexpr int OS = COUT + 4;                // pixel stride of the output tile parked in LDS (fused pool)
+  static constexpr int LDS_OUT_FLOATS = PX * OS;
+  static constexpr int LDS_FLOATS = LDS_PLANE_FLOATS;
   static_assert(COUT == 32 || COUT == 64, "4 waves cover 2 or 4 output-channel tiles");
   static_assert(CIN % 16 == 0, "input channels come in groups of 16");
 };
 
 // x [B,14,14,CIN]; w [25][COUT][CIN] (FLIP: tap t reads w[24-t]); y [B,14,14,COUT].
-template <int CIN, int COUT, int IMGS, bool FLIP, bool BIAS_RELU, bool POOLED>
+template <int CIN, int COUT, int IMGS, bool FLIP, bool BIAS_RELU, bool POOLED, bool POOLOUT>
 __global__ __launch_bounds__(256) void conv5x5_tile_kernel(Conv5x5Args a) {
   using G = C5<CIN, COUT, IMGS>;
   static_assert(!POOLED || (CIN == 64 && IMGS == 1), "pooled staging is the data-gradient form");
+  static_assert(!POOLOUT || (BIAS_RELU && COUT == 64), "the fused max pool follows the forward form");
   extern __shared__ __align__(16) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void conv5x5_tile_kernel(Conv5x5Args a) {
   const int n_tiles = (a.B + IMGS - 1) / IMGS;
 
   // zero the planes once: the halo is never written again
-  for (int i = tid; i < G::LDS_FLOATS / 4; i += 256) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < G::LDS_PLANE_FLOATS / 4; i += 256) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // window origin (top-left of the 5x5 footprint in the padded plane) of this lane's pixel in each
   // of the wave's pixel tiles, plus the lane's channel offset inside a 16-channel group
@@ -220,6 +224,7 @@ __global__ __launch_bounds__(256) void conv5x5_tile_kernel(Conv5x5Args a) {
 
     // lane holds output channels co0 + 4g .. +3 of pixel 16 t + n
     const int valid_px = min(G::PX, (a.B - tile * IMGS) * kImgPx);
+    if constexpr (POOLOUT) __syncthreads();   // the input planes are about to be overwritten by the outputs
     float* yt = a.y + (size_t)tile * G::PX * COUT + co0 + 4 * g;
 #pragma unroll
     for (int i = 0; i < G::NTW; ++i) {
@@ -236,8 +241,40 @@ __global__ __launch_bounds__(256) void conv5x5_tile_kernel(Conv5x5Args a) {
           o.z = fmaxf(o.z, 0.f);
           o.w = fmaxf(o.w, 0.f);
         }
-        *reinterpret_cast<float4*>(yt + (size_t)q * COUT) = o;
+        if constexpr (POOLOUT) *reinterpret_cast<float4*>(lds + q * G::OS + co0 + 4 * g) = o;
+        else *reinterpret_cast<float4*>(yt + (size_t)q * COUT) = o;
       }
+    }
+    if constexpr (POOLOUT) {
+      // 2x2 / 2 max pool of the tile from LDS: pooled maximum + winner position (first maximum
+      // wins, positions numbered (0,0) (0,1) (1,0) (1,1) as in maxpool2x2_fwd); the full-resolution
+      // activation is not written.
+      __syncthreads();
+      const int cells_valid = min(IMGS, a.B - tile * IMGS) * kCells;
+      for (int cc = tid; cc < IMGS * kCellChunks; cc += 256) {
+        const int cell = cc >> 4, c4 = cc & 15;
+        if (cell >= cells_valid) break;
+        const int img = cell / kCells, r = cell % kCells;
+        const float* o0 = lds + (img * kImgPx + 2 * (r / 7) * kHW + 2 * (r % 7)) * G::OS + 4 * c4;
+        const float4 v0 = *reinterpret_cast<const float4*>(o0);
+        const float4 v1 = *reinterpret_cast<const float4*>(o0 + G::OS);
+        const float4 v2 = *reinterpret_cast<const float4*>(o0 + kHW * G::OS);
+        const float4 v3 = *reinterpret_cast<const float4*>(o0 + (kHW + 1) * G::OS);
+        float4 best = v0;
+        unsigned arg = 0;
+        auto upd = [&](float& b, float v, unsigned pos, int e) {
+          if (v > b) { b = v; arg = (arg & ~(0xffu << (8 * e))) | (pos << (8 * e)); }
+        };
+        upd(best.x, v1.x, 1, 0); upd(best.y, v1.y, 1, 1); upd(best.z, v1.z, 1, 2); upd(best.w, v1.w, 1, 3);
+        upd(best.x, v2.x, 2, 0); upd(best.y, v2.y, 2, 1); upd(best.z, v2.z, 2, 2); upd(best.w, v2.w, 2, 3);
+        upd(best.x, v3.x, 3, 0); upd(best.y, v3.y, 3, 1); upd(best.z, v3.z, 3, 2); upd(best.w, v3.w, 3, 3);
+        const size_t off = ((size_t)tile * IMGS * kCells + cell) * 64 + 4 * c4;
+        *reinterpret_cast<float4*>(a.pool_out + off) = best;
+        *reinterpret_cast<unsigned*>(a.pool_arg_out + off) = arg;
+      }
+      // the planes' halo was overwritten: restore the zeros before the next tile is staged
+      __syncthreads();
+      for (int i = tid; i < G::LDS_PLANE_FLOATS / 4; i += 256) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 }
@@ -414,11 +451,11 @@ __global__ __launch_bounds__(256) void conv5x5_pack_kernel(Conv5x5PackArgs a) {
   a.out[i] = a.w[(size_t)tap * per_tap + ci * a.Cout + co];
 }
 
-template <int CIN, int COUT, int IMGS, bool FLIP, bool BIAS_RELU, bool POOLED = false>
+template <int CIN, int COUT, int IMGS, bool FLIP, bool BIAS_RELU, bool POOLED = false, bool POOLOUT = false>
 void launch_c5(const Conv5x5Args& a, hipStream_t stream) {
   using G = C5<CIN, COUT, IMGS>;
-  auto kernel = conv5x5_tile_kernel<CIN, COUT, IMGS, FLIP, BIAS_RELU, POOLED>;
-  const size_t shmem = (size_t)G::LDS_FLOATS * sizeof(float);
+  auto kernel = conv5x5_tile_kernel<CIN, COUT, IMGS, FLIP, BIAS_RELU, POOLED, POOLOUT>;
+  const size_t shmem = (size_t)(POOLOUT && G::LDS_OUT_FLOATS > G::LDS_PLANE_FLOATS ? G::LDS_OUT_FLOATS : G::LDS_PLANE_FLOATS) * sizeof(float);
   static const int bpc = [&] {
     ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), shmem);
     int nb = 0;
@@ -444,7 +481,14 @@ void conv5x5_tile(const Conv5x5Args& a, hipStream_t stream) {
     if (!a.bias) throw std::runtime_error("conv5x5_tile: the 32->64 forward form needs a bias");
     // two images per tile halve the padding of the last pixel tile; one image per tile keeps
     // every CU busy at small batches
-    if (a.imgs == 2 || (a.imgs == 0 && a.B >= 512)) return launch_c5<32, 64, 2, false, true>(a, stream);
+    const bool two = a.imgs == 2 || (a.imgs == 0 && a.B >= 512);
+    if (a.pool_out) {
+      if (!a.pool_arg_out) throw std::runtime_error("conv5x5_tile: the fused pool writes maxima and winner positions");
+      if (two) return launch_c5<32, 64, 2, false, true, false, true>(a, stream);
+      return launch_c5<32, 64, 1, false, true, false, true>(a, stream);
+    }
+    if (!a.y) throw std::runtime_error("conv5x5_tile: null output");
+    if (two) return launch_c5<32, 64, 2, false, true>(a, stream);
     return launch_c5<32, 64, 1, false, true>(a, stream);
   }
   if (a.Cin == 64 && a.Cout == 32 && a.flip) {

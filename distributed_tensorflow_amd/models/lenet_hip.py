@@ -2,7 +2,7 @@
 
 forward   conv1 + bias + ReLU + pool = one kernel (its 28x28x32 activation never reaches memory),
           conv2 = whole-image 5x5 MFMA kernel (input planes resident in LDS, filter streamed from
-          L2) with fused bias + ReLU, 2x2 SAME max pools that
+          L2) with fused bias + ReLU + max pool, pools that
           keep a 2-bit argmax, FC1 = split-K MFMA GEMM with bias + ReLU, Philox dropout whose mask
           is regenerated (not stored) in backward, FC2 GEMM with bias, fused softmax
           cross-entropy that also emits d(loss)/d(logits).
@@ -44,7 +44,8 @@ class LeNetHipStep(StepProgramBase):
         self.wpk2 = torch.empty(25 * 32 * 64, **f32)   # [tap][out][in], the whole-image kernel's operand
         self.p1 = torch.empty((B, 14, 14, 32), **f32)
         self.arg1 = torch.empty((B, 14, 14, 32), device=dev, dtype=torch.uint8)
-        self.a2 = torch.empty((B, 14, 14, 64), **f32)
+        self.p2 = torch.empty((B, 7, 7, 64), **f32)
+        self.arg2 = torch.empty((B, 7, 7, 64), device=dev, dtype=torch.uint8)
         self.h = torch.empty((B, 512), **f32)
         self.hd = torch.empty((B, 512), **f32)
         self.logits = torch.empty((B, NUM_LABELS), **f32)
@@ -68,8 +69,8 @@ class LeNetHipStep(StepProgramBase):
             # ---------------- forward
             # conv1 + bias + ReLU + pool in one kernel: the 28x28x32 activation is never written
             nv.conv1_pool_fwd(self.images, a.param("conv1_weights"), a.param("conv1_biases"), out=self.p1, arg=self.arg1)
-            nv.conv5x5_tile(self.p1, self.wpk2, bias=a.param("conv2_biases"), out=self.a2)
-            self.p2, self.arg2 = nv.maxpool2x2_fwd(self.a2)
+            # conv2 + bias + ReLU + pool: the 14x14x64 activation stays in LDS
+            nv.conv5x5_tile(self.p1, self.wpk2, bias=a.param("conv2_biases"), pool_out=(self.p2, self.arg2))
             flat = self.p2.view(B, -1)
             nv.gemm(flat, a.param("fc1_weights"), bias=a.param("fc1_biases"), relu=True, out=self.h)
             if self.dropout:

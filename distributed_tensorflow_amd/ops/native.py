@@ -313,13 +313,15 @@ def _pooled_operands(pooled, b: int, who: str) -> dict:
 
 
 def conv5x5_tile(x: Optional[torch.Tensor], w: torch.Tensor, *, bias: Optional[torch.Tensor] = None, flip: bool = False,
-                 out: Optional[torch.Tensor] = None, imgs: int = 0, pooled=None) -> torch.Tensor:
+                 out: Optional[torch.Tensor] = None, imgs: int = 0, pooled=None, pool_out=None) -> torch.Tensor:
     """5x5 stride-1 SAME convolution over [B,14,14,C] maps with whole images per workgroup.
     flip=False: x has 32 channels, w = conv5x5_pack(filter), returns relu(conv + bias) with 64
     channels. flip=True: x is the 64-channel output gradient, w = the [5,5,32,64] filter itself,
     returns the 32-channel input gradient (see csrc/kernels/conv.h: Conv5x5Args). With
     pooled=(dp, arg, p) (flip only, x=None) the output gradient is the 2x2 max-pool + ReLU backward
-    of dp [B,7,7,64], formed while staging instead of being read from memory."""
+    of dp [B,7,7,64], formed while staging instead of being read from memory. With
+    pool_out=(p, arg) (forward form) the kernel writes the 2x2 max pool of the activation
+    ([B,7,7,64] maxima, uint8 winner positions) instead of the activation and returns p."""
     require()
     if pooled is not None:
         if not flip or x is not None:
@@ -336,11 +338,20 @@ def conv5x5_tile(x: Optional[torch.Tensor], w: torch.Tensor, *, bias: Optional[t
         raise ValueError("conv5x5_tile: channel counts must be 32->64 (forward) or 64->32 (flip)")
     if imgs not in (0, 1, 2):
         raise ValueError("conv5x5_tile: imgs must be 0, 1 or 2")
-    if out is None:
-        out = torch.empty((b, 14, 14, cout), device=dev, dtype=torch.float32)
-    elif tuple(out.shape) != (b, 14, 14, cout):
-        raise ValueError("conv5x5_tile: out has the wrong shape")
-    d = dict(w=_chk(w, "w"), y=_chk(out, "y"), B=b, Cin=cin, Cout=cout, flip=int(flip), imgs=imgs)
+    d = dict(w=_chk(w, "w"), B=b, Cin=cin, Cout=cout, flip=int(flip), imgs=imgs)
+    if pool_out is not None:
+        pm, parg = pool_out
+        if flip or tuple(pm.shape) != (b, 7, 7, 64) or tuple(parg.shape) != (b, 7, 7, 64):
+            raise ValueError("conv5x5_tile: pool_out = (maxima, winner positions), each [B,7,7,64], forward form only")
+        d["pool_out"] = _chk(pm, "pool_out")
+        d["pool_arg_out"] = _chk(parg, "pool_arg_out", torch.uint8)
+        out = pm
+    else:
+        if out is None:
+            out = torch.empty((b, 14, 14, cout), device=dev, dtype=torch.float32)
+        elif tuple(out.shape) != (b, 14, 14, cout):
+            raise ValueError("conv5x5_tile: out has the wrong shape")
+        d["y"] = _chk(out, "y")
     if pooled is not None:
         d.update(_pooled_operands(pooled, b, "conv5x5_tile"))
     else:

@@ -135,6 +135,23 @@ def test_conv5x5_filter_gradient(b):
     close(dw2 - 1.0, wt.grad, tol=5e-4)
 
 
+@pytest.mark.parametrize("b,imgs", [(1, 1), (3, 2), (7, 1), (515, 0)])
+def test_conv5x5_forward_with_fused_pool(b, imgs):
+    x = rnd(b, 14, 14, 32)
+    wt = rnd(5, 5, 32, 64, scale=0.05)
+    bias = rnd(64, scale=0.3)
+    wpk = nv.conv5x5_pack(wt)
+    act = nv.conv5x5_tile(x, wpk, bias=bias, imgs=imgs)
+    want_p, want_arg = nv.maxpool2x2_fwd(act)
+    p = torch.full((b, 7, 7, 64), -1.0, device=DEV)
+    arg = torch.full((b, 7, 7, 64), 9, device=DEV, dtype=torch.uint8)
+    nv.conv5x5_tile(x, wpk, bias=bias, imgs=imgs, pool_out=(p, arg))
+    assert torch.equal(p, want_p) and torch.equal(arg, want_arg)
+    # a second tile-loop iteration must see clean halos again: same result when run twice
+    nv.conv5x5_tile(x, wpk, bias=bias, imgs=imgs, pool_out=(p, arg))
+    assert torch.equal(p, want_p)
+
+
 @pytest.mark.parametrize("b", [1, 6, 270])
 def test_conv5x5_backward_from_the_pooled_gradient(b):
     """Data and filter gradient of the second LeNet convolution computed straight from the
