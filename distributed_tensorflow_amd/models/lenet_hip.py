@@ -82,13 +82,15 @@ class LeNetHipStep(StepProgramBase):
             nv.softmax_xent(self.logits, self.labels, self.loss, self.dlogits if self.training else None, self.correct)
             if self.training:
                 # ---------------- backward
-                nv.gemm(hd, self.dlogits, trans_a=True, out=a.grad("fc2_weights"))
+                # the arena's gradients were zeroed by the step prologue: accumulating into them
+                # spares the split-K products their own clearing pass
+                nv.gemm(hd, self.dlogits, trans_a=True, out=a.grad("fc2_weights"), accumulate=True)
                 nv.col_sum(self.dlogits, a.grad("fc2_biases"))
                 nv.gemm(self.dlogits, a.param("fc2_weights"), trans_b=True, out=self.dh)
                 if self.dropout:
                     nv.dropout(self.dh, DROPOUT_KEEP, SEED, 0, out=self.dh, offset_dev=self.step_counter[0:1])
                 nv.relu_bwd(self.dh, self.h, out=self.dh)
-                nv.gemm(flat, self.dh, trans_a=True, out=a.grad("fc1_weights"))
+                nv.gemm(flat, self.dh, trans_a=True, out=a.grad("fc1_weights"), accumulate=True)
                 nv.col_sum(self.dh, a.grad("fc1_biases"))
                 # the FC block holds 97 % of the parameters: its bucket is final here
                 if num_buckets > 1:
