@@ -98,6 +98,17 @@ PYBIND11_MODULE(_hip, m) {
     return conv_bwd_fused(a, as_stream(stream));
   });
   m.def("conv_bwd_fused_supported", &conv_bwd_fused_supported);
+  m.def("conv_stem_fwd", [](const py::dict& d, uint64_t stream) {
+    ConvStemArgs a{};
+    P(x, const float); P(w, const float); P(y, float); P(sums, double); V(B);
+    conv_stem_fwd(a, as_stream(stream));
+  });
+  m.def("conv_stem_wgrad", [](const py::dict& d, uint64_t stream) {
+    ConvStemArgs a{};
+    P(x, const float); P(dy, const float); P(dw, float); V(slot_stride); V(B);
+    conv_stem_wgrad(a, as_stream(stream));
+  });
+  m.def("conv_stem_supported", &conv_stem_supported);
   m.def("conv5x5_tile", [](const py::dict& d, uint64_t stream) {
     Conv5x5Args a{};
     P(x, const float); P(w, const float); P(bias, const float); P(y, float);

@@ -133,6 +133,24 @@ constexpr int kBwdTileCounters = 32;   // 8 XCDs x up to 4 channel splits
 bool conv_bwd_fused_supported(int B, int H, int W, int C);
 size_t conv_bwd_fused(const ConvBwdFusedArgs& a, hipStream_t stream);
 
+// ---- stem of the CIFAR ResNet: 3x3, 3 -> 16 channels, SAME, 32x32 images (conv_stem.hip)
+// forward: y = conv(x, w), sums (nullable) += per-channel (sum, sum of squares) of y in the
+// statistic-slot layout; gradient: dw [3,3,3,16] += filter gradient from dy, with slot_stride != 0
+// into the copy of the workgroup's XCD. w / dw are the plain HWIO filter (no packing).
+struct ConvStemArgs {
+  const float* x;    // [B,32,32,3]
+  const float* w;    // [27][16], forward
+  float* y;          // [B,32,32,16], forward
+  double* sums;      // [kStatSlots][32], forward, nullable
+  const float* dy;   // [B,32,32,16], gradient
+  float* dw;         // [27][16], gradient
+  int slot_stride;
+  int B;
+};
+bool conv_stem_supported(int H, int W, int Cin, int Cout, int ks, int stride);
+void conv_stem_fwd(const ConvStemArgs& a, hipStream_t stream);
+void conv_stem_wgrad(const ConvStemArgs& a, hipStream_t stream);
+
 // ---- 5x5 stride-1 SAME convolution over 14x14 maps, whole images per workgroup (conv5x5_tile.hip)
 // Forward form (flip = 0): Cin 32 -> Cout 64, y = relu(conv(x, w) + bias), w = conv5x5_pack of
 // the HWIO filter ([25][Cout][Cin]). Data-gradient form (flip = 1): Cin 64 -> Cout 32 over the

@@ -34,13 +34,13 @@ constexpr int kCells = 49;                 // 7 x 7 pooled cells per image
 constexpr int kCellChunks = kCells * 16;   // 16-byte chunks (4 of 64 channels) per image
 constexpr int kNpc = (kCellChunks + 255) / 256;
 struct PooledChunk {
-  float4 dp, p;
+  floatx4 dp, p;
   unsigned arg;
 };
 __device__ __forceinline__ void pooled_fetch(const float* dp, const unsigned char* arg, const float* p, int img, int cc, PooledChunk& o) {
   const size_t off = ((size_t)img * kCells + (cc >> 4)) * 64 + 4 * (cc & 15);
-  o.dp = *reinterpret_cast<const float4*>(dp + off);
-  o.p = *reinterpret_cast<const float4*>(p + off);
+  o.dp = *reinterpret_cast<const floatx4*>(dp + off);
+  o.p = *reinterpret_cast<const floatx4*>(p + off);
   o.arg = *reinterpret_cast<const unsigned*>(arg + off);
 }
 // value of window position pos (0..3) for the chunk
@@ -320,7 +320,9 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(Conv5x5WgradArgs a) 
     const int c = tid + 256 * k;
     ydst[k] = ((c < kWgYChunks ? c : 0) >> 4) * kWgPsy + 4 * (c & 15);
   }
-  float4 pfx[kWgNpfX], pfy[POOLED ? 1 : kWgNpfY];
+  // native vector types: assigning a float4 (a struct) from global memory is a memcpy into the
+  // array, which then stays in scratch memory and makes the prefetch synchronous
+  floatx4 pfx[kWgNpfX], pfy[POOLED ? 1 : kWgNpfY];
   PooledChunk pc[POOLED ? kNpc : 1];
   int pdst[POOLED ? kNpc : 1];
   if constexpr (POOLED) {
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(Conv5x5WgradArgs a) 
     }
   }
   auto fetch = [&](int img) {
-    const float4* xs = reinterpret_cast<const float4*>(a.x + (size_t)img * kImgPx * 32);
+    const floatx4* xs = reinterpret_cast<const floatx4*>(a.x + (size_t)img * kImgPx * 32);
 #pragma unroll
     for (int k = 0; k < kWgNpfX; ++k)
       if (tid + 256 * k < kWgXChunks) pfx[k] = xs[tid + 256 * k];
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(Conv5x5WgradArgs a) 
       for (int k = 0; k < kNpc; ++k)
         if (tid + 256 * k < kCellChunks) pooled_fetch(a.pool_dp, a.pool_arg, a.pool_p, img, tid + 256 * k, pc[k]);
     } else {
-      const float4* ys = reinterpret_cast<const float4*>(a.dy + (size_t)img * kImgPx * 64);
+      const floatx4* ys = reinterpret_cast<const floatx4*>(a.dy + (size_t)img * kImgPx * 64);
 #pragma unroll
       for (int k = 0; k < kWgNpfY; ++k)
         if (tid + 256 * k < kWgYChunks) pfy[k] = ys[tid + 256 * k];
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(Conv5x5WgradArgs a) 
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kWgNpfX; ++k)
-      if (tid + 256 * k < kWgXChunks) *reinterpret_cast<float4*>(sx + xdst[k]) = pfx[k];
+      if (tid + 256 * k < kWgXChunks) *reinterpret_cast<floatx4*>(sx + xdst[k]) = pfx[k];
     if constexpr (POOLED) {
 #pragma unroll
       for (int k = 0; k < kNpc; ++k)
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(Conv5x5WgradArgs a) 
     } else {
 #pragma unroll
       for (int k = 0; k < kWgNpfY; ++k)
-        if (tid + 256 * k < kWgYChunks) *reinterpret_cast<float4*>(sy + ydst[k]) = pfy[k];
+        if (tid + 256 * k < kWgYChunks) *reinterpret_cast<floatx4*>(sy + ydst[k]) = pfy[k];
     }
     __syncthreads();
     if (img + (int)gridDim.x < a.B) fetch(img + gridDim.x);

@@ -204,7 +204,8 @@ class ResNetHipStep(StepProgramBase):
         a = self.arena
         nv.hip().pack_multi(a.params.data_ptr(), self.packed.data_ptr(), self._pack_table.data_ptr(), self._pack_n,
                             self._pack_blocks, nv.stream())
-        nv.conv_fprop(self.images, self._wpk("conv0/conv"), ks=3, cout=16, out=self.c0, out_sums=self.bn0.fwd.sums)
+        # stem: dedicated 3 -> 16 kernel over the plain filter (K = 27)
+        nv.conv_stem_fwd(self.images, a.param("conv0/conv"), out=self.c0, out_sums=self.bn0.fwd.sums)
         x, x_bn = self.c0, self.bn0
         for k, blk in enumerate(self.blocks):
             bn1 = self.bn0 if blk.first_block else self.bn1[k]
@@ -330,7 +331,8 @@ class ResNetHipStep(StepProgramBase):
                 end_bucket(marks[k], hi)
                 hi = marks[k]
         # stem: filter gradient of conv0 from the raw images
-        wgrad(self.images, self._d_c0, "conv0/conv", 1)
+        off0 = a.offsets["conv0/conv"]
+        nv.conv_stem_wgrad(self.images, self._d_c0, self._wslots[0, off0:off0 + 432].view(3, 3, 3, 16), slot_stride=a.total)
         end_bucket(0, hi)
 
     def _record(self, num_buckets: int) -> None:

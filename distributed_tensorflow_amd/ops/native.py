@@ -286,6 +286,39 @@ def conv_wgrad(
     return dw
 
 
+def conv_stem_fwd(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None, out_sums: Optional[torch.Tensor] = None):
+    """3x3 SAME convolution 3 -> 16 channels over [B,32,32,3] images with the plain [3,3,3,16]
+    filter; out_sums (a statistics block for 16 channels) receives the output's per-channel sums."""
+    require()
+    b = int(x.shape[0])
+    if tuple(x.shape[1:]) != (32, 32, 3) or tuple(w.shape) != (3, 3, 3, 16):
+        raise ValueError("conv_stem_fwd: expected [B,32,32,3] images and a [3,3,3,16] filter")
+    if out is None:
+        out = torch.empty((b, 32, 32, 16), device=x.device, dtype=torch.float32)
+    elif tuple(out.shape) != (b, 32, 32, 16):
+        raise ValueError("conv_stem_fwd: out has the wrong shape")
+    d = dict(x=_chk(x, "x"), w=_chk(w, "w"), y=_chk(out, "y"), B=b)
+    if out_sums is not None:
+        if out_sums.numel() != STAT_SLOTS * 32:
+            raise ValueError("conv_stem_fwd: out_sums must be a statistics block of 16 channels")
+        d["sums"] = _chk(out_sums, "sums", torch.float64)
+    hip().conv_stem_fwd(d, stream())
+    return out
+
+
+def conv_stem_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, slot_stride: int = 0) -> None:
+    """dw [3,3,3,16] += filter gradient of conv_stem_fwd (per-XCD copies with slot_stride)."""
+    require()
+    b = int(x.shape[0])
+    if tuple(x.shape[1:]) != (32, 32, 3) or tuple(dy.shape) != (b, 32, 32, 16) or dw.numel() != 27 * 16:
+        raise ValueError("conv_stem_wgrad: expected x [B,32,32,3], dy [B,32,32,16], dw [3,3,3,16]")
+    if slot_stride:
+        last = (dw.storage_offset() + (STAT_SLOTS - 1) * slot_stride + dw.numel()) * 4
+        if slot_stride < dw.numel() or last > dw.untyped_storage().nbytes():
+            raise ValueError("conv_stem_wgrad: the slot copies do not fit dw's storage")
+    hip().conv_stem_wgrad(dict(x=_chk(x, "x"), dy=_chk(dy, "dy"), dw=_chk(dw, "dw"), slot_stride=slot_stride, B=b), stream())
+
+
 def conv5x5_tile_supported(h: int, w_: int, cin: int, cout: int) -> bool:
     return bool(hip().conv5x5_tile_supported(h, w_, cin, cout))
 

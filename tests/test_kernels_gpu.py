@@ -103,6 +103,26 @@ def test_conv_fprop_bias_relu():
     close(nv.conv_fprop(x, nv.pack_weights(wt), ks=5, cout=64, epi_mode=nv.EPI_BIAS_RELU, bias=bias), want)
 
 
+@pytest.mark.parametrize("b", [1, 3, 70, 300])
+def test_conv_stem_forward_statistics_and_filter_gradient(b):
+    x = rnd(b, 32, 32, 3)
+    wt = rnd(3, 3, 3, 16, scale=0.3).requires_grad_(True)
+    want = ref.conv2d_same(x, wt, 1)
+    sums = nv.new_stats(16)
+    got = nv.conv_stem_fwd(x, wt.detach(), out_sums=sums)
+    close(got, want.detach())
+    tot = nv.stats_total(sums)
+    flat = want.detach().reshape(-1, 16).double()
+    close(tot[:16], flat.sum(0), tol=1e-5)
+    close(tot[16:], (flat * flat).sum(0), tol=1e-5)
+    dy = rnd(b, 32, 32, 16)
+    want.backward(dy)
+    slots = torch.zeros(nv.STAT_SLOTS, 512, device=DEV)
+    nv.conv_stem_wgrad(x, dy, slots[0, :432].view(3, 3, 3, 16), slot_stride=512)
+    close(slots.sum(0)[:432].view(3, 3, 3, 16), wt.grad, tol=5e-4)
+    assert float(slots[:, 432:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("b,imgs", [(1, 1), (3, 1), (3, 2), (4, 2), (37, 0), (1030, 0)])
 def test_conv5x5_tile_forward(b, imgs):
     """Whole-image 5x5 kernel (LeNet conv2 shape): bias + ReLU epilogue, odd batches so the last
