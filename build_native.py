@@ -84,6 +84,8 @@ def build_hip(force: bool = False, jobs: int = 8) -> Path:
         hipcc, "-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math",
         "-I", str(CSRC), "-I", py_inc, "-I", _pybind_include(), "-fvisibility=hidden", "-Wno-unused-result",
     ]
+    if os.environ.get("DTF_CONV_DEBUG") == "1":   # run-time ablation switches of the band kernels (bench/conv_ablation.py)
+        common.append("-DDTF_CONV_DEBUG=1")
     srcs = sorted((CSRC / "kernels").glob("*.hip")) + sorted((CSRC / "comm").glob("*.hip")) + [
         CSRC / "runtime" / "program.cc", CSRC / "bindings_hip.cc",
     ]

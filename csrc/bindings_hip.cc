@@ -154,6 +154,17 @@ PYBIND11_MODULE(_hip, m) {
     pack_multi(a, total_blocks, as_stream(stream));
   });
   m.attr("PACK_ENTRY_BYTES") = (int)sizeof(PackEntry);
+  m.def("zero_multi", [](const std::vector<std::pair<uint64_t, uint64_t>>& bufs, uint64_t stream) {
+    if (bufs.empty() || bufs.size() > (size_t)kZeroMultiMax) throw std::runtime_error("zero_multi: 1..8 buffers");
+    ZeroMultiArgs a{};
+    a.count = (int)bufs.size();
+    for (int i = 0; i < a.count; ++i) {
+      if (bufs[i].second & 15) throw std::runtime_error("zero_multi: sizes must be multiples of 16 bytes");
+      a.ptr[i] = reinterpret_cast<void*>(bufs[i].first);
+      a.chunks[i] = bufs[i].second / 16;
+    }
+    zero_multi(a, as_stream(stream));
+  });
 
   // ---------------------------------------------------------------- batch norm
   m.def("bn_stats", [](const py::dict& d, uint64_t stream) {

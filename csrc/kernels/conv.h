@@ -5,6 +5,14 @@
 #pragma once
 #include "common.h"
 
+// The `debug_skip` switches of the band kernels (timing experiments: parts of a kernel switched
+// off at run time) cost branches and default-value moves in every tile, so they only exist in
+// builds made with DTF_CONV_DEBUG=1 (build_native.py reads it from the environment).
+#ifndef DTF_CONV_DEBUG
+#define DTF_CONV_DEBUG 0
+#endif
+#define DTF_DEBUG_SKIP(a) (DTF_CONV_DEBUG ? (a).debug_skip : 0)
+
 namespace dtf {
 
 enum InMode : int { IN_RAW = 0, IN_BNRELU = 1 };

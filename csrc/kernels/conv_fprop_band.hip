@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_band_kernel(ConvFpropArgs a
           for (int j = 0; j < NT; ++j) {
             pre_rv[it][i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
             pre_xv[it][i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-            if (!(a.debug_skip & 4)) {
+            if (!(DTF_DEBUG_SKIP(a) & 4)) {
               if (want_res) pre_rv[it][i][j] = *reinterpret_cast<const floatx4*>(a.res + oo + j * 16);
               if (BWD) {
                 pre_xv[it][i][j] = *reinterpret_cast<const floatx4*>(a.mask_src + oo + j * 16);
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_band_kernel(ConvFpropArgs a
     for (int k = 0; k < G::NPF; ++k) {
       const int iy = base_row + in_row[k];
       floatx4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < a.H && !(a.debug_skip & 2)) {
+      if (iy >= 0 && iy < a.H && !(DTF_DEBUG_SKIP(a) & 2)) {
         v = *reinterpret_cast<const floatx4*>(in0 + in_goff[k]);
         okbits |= 1u << k;
       }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_band_kernel(ConvFpropArgs a
         }
       }
 
-      if (!(a.debug_skip & 1)) {
+      if (!(DTF_DEBUG_SKIP(a) & 1)) {
         // Operand fragments are double buffered in registers: the LDS reads of k-group g+1 are in
         // flight while the MFMAs of k-group g execute; the scheduling barriers pin that order.
         floatx4 av[2][MTW], bv[2][NT];
@@ -362,14 +362,14 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_band_kernel(ConvFpropArgs a
               st2[j][r] += v[r] * ((x[r] - e_mean[j][r]) * e_rstd[j][r]);
             }
           }
-          if (!(a.debug_skip & 4)) *reinterpret_cast<floatx4*>(a.out + ooff[i] + j * 16) = v;
+          if (!(DTF_DEBUG_SKIP(a) & 4)) *reinterpret_cast<floatx4*>(a.out + ooff[i] + j * 16) = v;
         }
       }
     }
     __syncthreads();   // all waves are done reading s_in before the next tile overwrites it
   }
 
-  if (a.out_sums && !(a.debug_skip & 8)) {
+  if (a.out_sums && !(DTF_DEBUG_SKIP(a) & 8)) {
     block_stat_flush<NT, 4>(smem, st1, st2, a.out_sums, a.Cout, z * NT * 16);
   }
 }

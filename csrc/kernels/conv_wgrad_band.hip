@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(ConvWgradArgs a
     for (int k = 0; k < G::NPF_IN; ++k) {
       const int iy = vy0 + in_row[k];
       floatx4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < a.H && !(a.debug_skip & 2)) {
+      if (iy >= 0 && iy < a.H && !(DTF_DEBUG_SKIP(a) & 2)) {
         v = *reinterpret_cast<const floatx4*>(in0 + in_goff[k]);
         okbits |= 1u << k;
       }
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(ConvWgradArgs a
 #pragma unroll
     for (int k = 0; k < G::NPF_G; ++k) {
       floatx4 v = {0.f, 0.f, 0.f, 0.f};
-      if (g_goff[k] >= 0 && !(a.debug_skip & 2)) v = *reinterpret_cast<const floatx4*>(g0 + g_goff[k]);
+      if (g_goff[k] >= 0 && !(DTF_DEBUG_SKIP(a) & 2)) v = *reinterpret_cast<const floatx4*>(g0 + g_goff[k]);
       pf_g[k] = v;
     }
   };
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(ConvWgradArgs a
     __syncthreads();
     if (t + 1 < t_end) load_band(t + 1);   // in flight during the MFMA loop
 
-    if (!(a.debug_skip & 1)) {
+    if (!(DTF_DEBUG_SKIP(a) & 1)) {
       // Two fragment sets alternate: while the nine-tap MFMA group of one k-step executes, the LDS
       // reads of the next k-step are already in flight. The scheduling barriers keep the compiler
       // from sinking the reads below the MFMAs (it otherwise waits for LDS once per k-step).
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(ConvWgradArgs a
     __syncthreads();   // all waves are done with this band's LDS tile
   }
 
-  if (a.debug_skip & 4) return;
+  if (DTF_DEBUG_SKIP(a) & 4) return;
   // ---- flush: accumulators -> LDS (one pass), sum the pixel-split partials, coalesced atomics ----
   constexpr int ROWS = CI_T * 16;
   constexpr int RS = G::RED_STRIDE;

@@ -304,6 +304,18 @@ __global__ __launch_bounds__(256) void crop_whiten_kernel(CropWhitenArgs a) {
   for (int i = threadIdx.x; i < per; i += blockDim.x) dst[i] = (dst[i] - s_mean) * s_inv;
 }
 
+__global__ __launch_bounds__(256) void zero_multi_kernel(ZeroMultiArgs a) {
+  unsigned long long total = 0;
+  for (int i = 0; i < a.count; ++i) total += a.chunks[i];
+  const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+  for (unsigned long long c = (unsigned long long)blockIdx.x * 256 + threadIdx.x; c < total; c += stride) {
+    unsigned long long r = c;
+    int seg = 0;
+    while (r >= a.chunks[seg]) r -= a.chunks[seg++];   // total bounds c, so seg < count
+    reinterpret_cast<floatx4*>(a.ptr[seg])[r] = floatx4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 __global__ __launch_bounds__(256) void pack_multi_kernel(PackMultiArgs a) {
   // Find this block's table entry (entries are sorted by first_block).
   int e = 0;
@@ -398,6 +410,17 @@ void tf_histogram(const HistogramArgs& a, hipStream_t stream) {
 }
 void crop_whiten(const CropWhitenArgs& a, hipStream_t stream) {
   launch("crop_whiten", crop_whiten_kernel, dim3(a.B), dim3(256), 0, stream, a);
+}
+void zero_multi(const ZeroMultiArgs& a, hipStream_t stream) {
+  if (a.count < 1 || a.count > kZeroMultiMax) throw std::runtime_error("zero_multi: 1..8 buffers");
+  unsigned long long total = 0;
+  for (int i = 0; i < a.count; ++i) {
+    if (!a.ptr[i] || (reinterpret_cast<uintptr_t>(a.ptr[i]) & 15)) throw std::runtime_error("zero_multi: buffers must be 16-byte aligned");
+    total += a.chunks[i];
+  }
+  if (total == 0) return;
+  const unsigned long long want = (total + 255) / 256;
+  launch("zero_multi", zero_multi_kernel, dim3((unsigned)(want > 2048 ? 2048 : want)), dim3(256), 0, stream, a);
 }
 void pack_multi(const PackMultiArgs& a, int total_blocks, hipStream_t stream) {
   launch("pack_multi", pack_multi_kernel, dim3(total_blocks), dim3(256), 0, stream, a);

@@ -214,4 +214,10 @@ struct PackEntry { long long w_off; long long out_off; int ks, Cin, Cout, transp
 struct PackMultiArgs { const float* params; float* packed; const PackEntry* table; int n_entries; };
 void pack_multi(const PackMultiArgs& a, int total_blocks, hipStream_t stream);
 
+// Zeroes up to kZeroMultiMax buffers in one launch (the per-step clears of a training program:
+// statistics, counters, loss, gradients). Every buffer is 16-byte aligned; sizes count 16-byte chunks.
+constexpr int kZeroMultiMax = 8;
+struct ZeroMultiArgs { void* ptr[kZeroMultiMax]; unsigned long long chunks[kZeroMultiMax]; int count; };
+void zero_multi(const ZeroMultiArgs& a, hipStream_t stream);
+
 }  // namespace dtf

@@ -339,10 +339,7 @@ class ResNetHipStep(StepProgramBase):
         p = self.program
         p.begin_record()
         try:
-            nv.memset_zero(self.stats)
-            if self.training:
-                nv.memset_zero(self._tile_ctr)
-            self._record_prologue()
+            self._record_prologue([self.stats, self._tile_ctr] if self.training and self.dynamic_tiles else [self.stats])
             self._record_forward()
             if self.training:
                 self._record_backward(num_buckets)

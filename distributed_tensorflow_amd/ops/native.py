@@ -662,6 +662,20 @@ def memset_zero(t: torch.Tensor):
     hip().memset(t.data_ptr(), 0, t.numel() * t.element_size(), stream())
 
 
+ZERO_MULTI_MAX = 8
+
+
+def zero_multi(tensors) -> None:
+    """Zeroes several buffers in one launch (at most 8; each 16-byte aligned, a multiple of 16 bytes)."""
+    require()
+    bufs = []
+    for t in tensors:
+        if not (t.is_cuda and t.is_contiguous()):
+            raise ValueError("zero_multi: contiguous device tensors only")
+        bufs.append((t.data_ptr(), t.numel() * t.element_size()))
+    hip().zero_multi(bufs, stream())
+
+
 # ----------------------------------------------------------------------------- elementwise & friends
 def add_relu_fwd(a, b, relu_first: bool, out=None):
     require()

@@ -33,11 +33,22 @@ class StepProgramBase:
         self.program = nv.hip().Program()
         self.num_segments = 1
 
-    def _record_prologue(self) -> None:
-        nv.memset_zero(self.scalars)
-        nv.hip().memset(self._correct_buf.data_ptr(), 0, 16, nv.stream())
+    def _record_prologue(self, also_zero=()) -> None:
+        """Clears everything a step accumulates into (loss, top-1 count, gradients, `also_zero`) in
+        one launch; buffers that are not 16-byte granular get a memset of their own."""
+        bufs = [self.scalars, self._correct_buf] + list(also_zero)
         if self.training:
-            nv.memset_zero(self.arena.grads)
+            bufs.append(self.arena.grads)
+        batch = []
+        for t in bufs:
+            if t.numel() == 0:
+                continue
+            if t.data_ptr() % 16 == 0 and (t.numel() * t.element_size()) % 16 == 0:
+                batch.append(t)
+            else:
+                nv.memset_zero(t)
+        for i in range(0, len(batch), nv.ZERO_MULTI_MAX):
+            nv.zero_multi(batch[i:i + nv.ZERO_MULTI_MAX])
 
     def _record_optimizer(self) -> None:
         a = self.arena

@@ -711,3 +711,24 @@ def test_program_record_run_and_graph_replay():
         prog.replay(s.cuda_stream)
         s.synchronize()
     assert float(x[n - 1]) == 18.0 * 36.0
+
+
+def test_zero_multi_clears_every_buffer_and_nothing_else():
+    sizes = [4, 20, 1 << 16, 272476 // 4 * 4, 8]
+    guard = 8
+    bufs, views = [], []
+    for i, n in enumerate(sizes):
+        dt = torch.float64 if i == 1 else (torch.int32 if i == 4 else torch.float32)
+        full = torch.ones(n + 2 * guard, device="cuda", dtype=dt)
+        bufs.append(full)
+        views.append(full[guard:guard + n])
+    views = [v for v in views if v.data_ptr() % 16 == 0 and (v.numel() * v.element_size()) % 16 == 0]
+    assert len(views) >= 4
+    nv.zero_multi(views)
+    torch.cuda.synchronize()
+    for v in views:
+        assert int((v != 0).sum()) == 0
+    for full in bufs:
+        assert bool((full[:guard] == 1).all()) and bool((full[-guard:] == 1).all())
+    with pytest.raises(Exception):
+        nv.zero_multi([bufs[0][1:5]])
