@@ -195,7 +195,7 @@ PYBIND11_MODULE(_hip, m) {
     HeadFwdArgs a{};
     P(x, const float); a.bn = as_bn(d, "bn"); P(fc_w, const float); P(fc_b, const float); P(labels, const int);
     P(feat, float); P(logits, float); P(dlogits, float); P(loss, float); P(correct, int);
-    V(B); V(HW); V(C); V(K);
+    V(B); V(HW); V(C); V(K); V(slots);
     head_fwd(a, as_stream(stream));
   });
   m.def("head_bwd", [](const py::dict& d, uint64_t stream) {

@@ -37,20 +37,42 @@ __device__ __forceinline__ void xent_row(const float* z, int K, int label, float
 
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
   __shared__ float s_scale[kMaxC], s_shift[kMaxC], s_feat[kMaxC], s_logit[kMaxK];
+  __shared__ float s_w[kMaxC * kMaxK / 4], s_part[8][kMaxK + 1];
   const int n = blockIdx.x;
-  const int C = a.C, C4 = C >> 2, tid = threadIdx.x;
+  const int C = a.C, C4 = C >> 2, K = a.K, tid = threadIdx.x;
+  // everything the block will need is requested up front: the activation chunks, the FC weights
+  // (to LDS, when they fit) and the BatchNorm statistics; the block's time is one memory round trip
+  // plus the short dependent chain behind it
+  const floatx4* x4 = reinterpret_cast<const floatx4*>(a.x + (size_t)n * a.HW * C);
+  const int n4 = a.HW * C4;
+  constexpr int kPre = 4;
+  floatx4 pre[kPre];
+#pragma unroll
+  for (int u = 0; u < kPre; ++u) {
+    const int i = tid + 256 * u;
+    pre[u] = i < n4 ? x4[i] : floatx4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool w_in_lds = C * K <= kMaxC * kMaxK / 4;
+  if (w_in_lds)
+    for (int e = tid; e < C * K; e += 256) s_w[e] = a.fc_w[e];
+  const float* fw = w_in_lds ? s_w : a.fc_w;
   for (int c = tid; c < C; c += 256) {
     float m, r;
     bn_coeffs(a.bn, c, C, s_scale[c], s_shift[c], m, r);
     s_feat[c] = 0.f;
   }
   __syncthreads();
-  const floatx4* x4 = reinterpret_cast<const floatx4*>(a.x + (size_t)n * a.HW * C);
-  const int n4 = a.HW * C4;
   // 256 % C4 == 0 is guaranteed by the launcher, so each thread keeps one channel group.
   const int c = (tid % C4) * 4;
   floatx4 s = {0, 0, 0, 0};
-  for (int i = tid; i < n4; i += 256) {
+#pragma unroll
+  for (int u = 0; u < kPre; ++u) {
+    if (tid + 256 * u < n4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += fmaxf(pre[u][e] * s_scale[c + e] + s_shift[c + e], 0.f);
+    }
+  }
+  for (int i = tid + 256 * kPre; i < n4; i += 256) {
     const floatx4 v = x4[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) s[e] += fmaxf(v[e] * s_scale[c + e] + s_shift[c + e], 0.f);
@@ -65,21 +87,40 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
     a.feat[(size_t)n * C + cc] = f;
   }
   __syncthreads();
-  if (tid < a.K) {
-    float z = a.fc_b[tid];
-    for (int cc = 0; cc < C; ++cc) z += s_feat[cc] * a.fc_w[cc * a.K + tid];
-    s_logit[tid] = z;
-    a.logits[(size_t)n * a.K + tid] = z;
+  // logits: thread (part, k) sums every 8th channel, 8 partial sums per class
+  {
+    const int k = tid & 31, part = tid >> 5;   // 8 parts x 32 class slots
+    float z = 0.f;
+    if (k < K)
+      for (int cc = part; cc < C; cc += 8) z += s_feat[cc] * fw[cc * K + k];
+    if (k < K) s_part[part][k] = z;
   }
   __syncthreads();
-  if (tid == 0) {
-    float dz[kMaxK];
-    float loss;
-    int hit;
-    xent_row(s_logit, a.K, a.labels[n], 1.f / (float)a.B, dz, loss, hit);
-    for (int k = 0; k < a.K; ++k) a.dlogits[(size_t)n * a.K + k] = dz[k];
-    atomicAdd(a.loss, loss / (float)a.B);
-    if (a.correct && hit) atomicAdd(a.correct, 1);
+  if (tid < K) {
+    float z = a.fc_b[tid];
+#pragma unroll
+    for (int part = 0; part < 8; ++part) z += s_part[part][tid];
+    s_logit[tid] = z;
+    a.logits[(size_t)n * K + tid] = z;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    // softmax cross-entropy of the row by one wave, lane = class (K <= 32)
+    const int label = a.labels[n];
+    const float z = tid < K ? s_logit[tid] : -3.0e38f;
+    float mx = z;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    const float e = tid < K ? __expf(z - mx) : 0.f;
+    const float se = wave_sum(e);
+    const float zl = __shfl(z, label);
+    if (tid < K) a.dlogits[(size_t)n * K + tid] = (e / se - (tid == label ? 1.f : 0.f)) / (float)a.B;
+    const unsigned long long at_max = __ballot(tid < K && z == mx);
+    if (tid == 0) {
+      const int slot = n & (a.slots - 1);
+      atomicAdd(a.loss + slot, (mx + __logf(se) - zl) / (float)a.B);
+      if (a.correct && (__ffsll((long long)at_max) - 1) == label) atomicAdd(a.correct + slot, 1);   // first maximum wins, as argmax does
+    }
   }
 }
 
@@ -89,6 +130,16 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
   __shared__ float s_dz[kMaxK];
   const int n = blockIdx.x;
   const int C = a.C, C4 = C >> 2, K = a.K, tid = threadIdx.x;
+  // the activation chunks are requested before the short dependent chain of coefficients
+  const floatx4* x4 = reinterpret_cast<const floatx4*>(a.x + (size_t)n * a.HW * C);
+  const int n4 = a.HW * C4;
+  constexpr int kPre = 4;
+  floatx4 pre[kPre];
+#pragma unroll
+  for (int u = 0; u < kPre; ++u) {
+    const int i = tid + 256 * u;
+    pre[u] = i < n4 ? x4[i] : floatx4{0.f, 0.f, 0.f, 0.f};
+  }
   if (tid < K) s_dz[tid] = a.dlogits[(size_t)n * K + tid];
   for (int c = tid; c < C; c += 256) {
     bn_coeffs(a.bn, c, C, s_scale[c], s_shift[c], s_mean[c], s_rstd[c]);
@@ -103,13 +154,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
     s_df[c] = d * inv_hw;
   }
   __syncthreads();
-  const floatx4* x4 = reinterpret_cast<const floatx4*>(a.x + (size_t)n * a.HW * C);
   floatx4* g4 = reinterpret_cast<floatx4*>(a.g + (size_t)n * a.HW * C);
-  const int n4 = a.HW * C4;
   const int c = (tid % C4) * 4;
   floatx4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
-  for (int i = tid; i < n4; i += 256) {
-    const floatx4 x = x4[i];
+  auto one = [&](int i, const floatx4& x) {
     floatx4 g;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -118,7 +166,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
       s2[e] += g[e] * ((x[e] - s_mean[c + e]) * s_rstd[c + e]);
     }
     g4[i] = g;
-  }
+  };
+#pragma unroll
+  for (int u = 0; u < kPre; ++u)
+    if (tid + 256 * u < n4) one(tid + 256 * u, pre[u]);
+  for (int i = tid + 256 * kPre; i < n4; i += 256) one(i, x4[i]);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     atomicAdd(&s_red[c + e], s1[e]);
@@ -191,6 +243,7 @@ __global__ __launch_bounds__(256) void top1_kernel(Top1Args a) {
 void head_fwd(const HeadFwdArgs& a, hipStream_t stream) {
   if (a.K > kMaxK || a.C > kMaxC || (a.C & 3) || (256 % (a.C / 4)) != 0)
     throw std::runtime_error("head_fwd: unsupported C/K");
+  if (a.slots < 1 || (a.slots & (a.slots - 1))) throw std::runtime_error("head_fwd: slots must be a power of two");
   launch("head_fwd", head_fwd_kernel, dim3(a.B), dim3(256), 0, stream, a);
 }
 

@@ -70,9 +70,10 @@ struct HeadFwdArgs {
   float* feat;          // [B, C]   pooled features (saved for backward)
   float* logits;        // [B, K]
   float* dlogits;       // [B, K]   (softmax - onehot) / B
-  float* loss;          // [1] += mean cross-entropy
-  int* correct;         // [1] += number of top-1 hits (nullable)
+  float* loss;          // [slots] += mean cross-entropy; image n adds to element n % slots, the loss is their sum
+  int* correct;         // [slots] += number of top-1 hits, spread the same way (nullable)
   int B, HW, C, K;
+  int slots;            // power of two; one atomic target for 1024 blocks serialises them (~25 ns each)
 };
 void head_fwd(const HeadFwdArgs& a, hipStream_t stream);
 

@@ -223,7 +223,7 @@ class ResNetHipStep(StepProgramBase):
                           out=self.y[k], out_sums=nxt.fwd.sums, **res)
             x = self.y[k]
         nv.head_fwd(x, self.bnf.fwd, a.param("fc/fc_weights"), a.param("fc/fc_bias"), self.labels, self.feat,
-                    self.logits, self.dlogits, self.loss, self.correct)
+                    self.logits, self.dlogits, self.scalars, self._correct_buf)
 
     def _record_backward(self, num_buckets: int) -> None:
         a = self.arena

@@ -558,6 +558,8 @@ def bn_bwd_apply(g, x, bn: BnState, gsums, *, dgamma=None, dbeta=None, res_mode=
 
 # ----------------------------------------------------------------------------- head / loss
 def head_fwd(x, bn: BnState, fc_w, fc_b, labels, feat, logits, dlogits, loss, correct=None):
+    """`loss` (and `correct`) may have a power-of-two number of elements: image n accumulates into
+    element n % len, the result is their sum (one shared element serialises the blocks' atomics)."""
     require()
     b, h, w_, c = x.shape
     k = fc_w.shape[1]
@@ -567,8 +569,10 @@ def head_fwd(x, bn: BnState, fc_w, fc_b, labels, feat, logits, dlogits, loss, co
         raise ValueError("head_fwd: output shape mismatch")
     d = dict(x=_chk(x, "x"), bn=bn.ref(), fc_w=_chk(fc_w, "fc_w"), fc_b=_chk(fc_b, "fc_b"),
              labels=_chk(labels, "labels", torch.int32), feat=_chk(feat, "feat"), logits=_chk(logits, "logits"),
-             dlogits=_chk(dlogits, "dlogits"), loss=_chk(loss, "loss"), B=b, HW=h * w_, C=c, K=k)
+             dlogits=_chk(dlogits, "dlogits"), loss=_chk(loss, "loss"), B=b, HW=h * w_, C=c, K=k, slots=loss.numel())
     if correct is not None:
+        if correct.numel() != loss.numel():
+            raise ValueError("head_fwd: loss and correct need the same number of slots")
         d["correct"] = _chk(correct, "correct", torch.int32)
     hip().head_fwd(d, stream())
 

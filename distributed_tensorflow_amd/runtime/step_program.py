@@ -15,15 +15,18 @@ from ..ops import native as nv
 
 
 class StepProgramBase:
+    SCALAR_SLOTS = 64
     # set by subclasses before _init_common(): self.arena, self.device, self.batch, self.training, self.optimizer
     def _init_common(self, image_shape: Tuple[int, ...]) -> None:
         dev, B = self.device, self.batch
         f32 = dict(device=dev, dtype=torch.float32)
         self.images = torch.zeros((B,) + tuple(image_shape), **f32)
         self.labels = torch.zeros(B, device=dev, dtype=torch.int32)
-        self.scalars = torch.zeros(4, **f32)                  # [0] = loss
+        # loss and top-1 count are sums over SCALAR_SLOTS elements: kernels that add one value per
+        # image spread them, since atomics on a single address serialise
+        self.scalars = torch.zeros(self.SCALAR_SLOTS, **f32)
         self.loss = self.scalars[0:1]
-        self._correct_buf = torch.zeros(4, device=dev, dtype=torch.int32)
+        self._correct_buf = torch.zeros(self.SCALAR_SLOTS, device=dev, dtype=torch.int32)
         self.correct = self._correct_buf[0:1]
         self.hyper = torch.zeros(nv.HYPER_SLOTS, **f32)
         self.hyper_host = torch.zeros(nv.HYPER_SLOTS, dtype=torch.float32).pin_memory()
@@ -96,10 +99,10 @@ class StepProgramBase:
             nv.memset_zero(self.arena.grads[lo:hi])
 
     def loss_value(self) -> float:
-        return float(self.loss.item())
+        return float(self.scalars.sum().item())
 
     def correct_count(self) -> int:
-        return int(self.correct.item())
+        return int(self._correct_buf.sum().item())
 
     @property
     def kernel_count(self) -> int:

@@ -489,7 +489,8 @@ def test_bn_bwd_apply_shortcut_a():
     close(nv.shortcut_a_bwd(dy_block, tuple(x.shape)), want_sc)
 
 
-def test_head_fwd_bwd():
+@pytest.mark.parametrize("slots", [1, 8])
+def test_head_fwd_bwd(slots):
     b, hw, c, k = 9, 8, 64, 10
     x = rnd(b, hw, hw, c, scale=1.5)
     gamma, beta = rnd(c).abs() + 0.5, rnd(c, scale=0.3)
@@ -507,12 +508,12 @@ def test_head_fwd_bwd():
     feat = torch.empty(b, c, device=DEV)
     logits = torch.empty(b, k, device=DEV)
     dlogits = torch.empty(b, k, device=DEV)
-    loss = torch.zeros(1, device=DEV)
-    correct = torch.zeros(1, device=DEV, dtype=torch.int32)
+    loss = torch.zeros(slots, device=DEV)
+    correct = torch.zeros(slots, device=DEV, dtype=torch.int32)
     nv.head_fwd(x, st, fc_w, fc_b, labels, feat, logits, dlogits, loss, correct)
     close(logits, logits_ref)
-    close(loss, loss_ref.reshape(1))
-    assert int(correct.item()) == ref.top1_hits(logits_ref, labels)
+    close(loss.sum().reshape(1), loss_ref.reshape(1))
+    assert int(correct.sum().item()) == ref.top1_hits(logits_ref, labels)
 
     g = torch.empty_like(x)
     gs = nv.new_stats(c, DEV)
