@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Where does a conv kernel's time go? Times the forward conv of each ResNet shape with parts
 switched off (no MFMA / no input loads / no epilogue traffic), 20 launches per hipGraph replay so
-host launch overhead is excluded."""
+host launch overhead is excluded.
+
+The band kernels only carry the run-time switches in a build made with DTF_CONV_DEBUG=1
+(`DTF_CONV_DEBUG=1 python build_native.py --only hip --force`); in the normal build `debug_skip` is
+ignored by them and every column times the full kernel."""
 from __future__ import annotations
 
 import os
