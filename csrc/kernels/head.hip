@@ -1,11 +1,11 @@
 // Classifier head and loss kernels.
 //
 // head_fwd fuses BatchNorm + ReLU + global average pool + fully connected + softmax
-// cross-entropy for one image per block: the 8x8x64 activation is read exactly once and only
+// cross-entropy for one image per wave: the 8x8x64 activation is read exactly once and only
 // the pooled features, logits and d(loss)/d(logits) are written.
 // head_bwd fuses the FC data gradient, the broadcast through the average pool, the ReLU mask
-// and the two BatchNorm-backward reductions; the FC parameter gradients are reduced per block
-// and leave with one atomic per element and block.
+// and the two BatchNorm-backward reductions (combined per block of four images before they
+// leave as fp64 atomics); the FC parameter gradients are a separate small kernel.
 #include "ops.h"
 
 namespace dtf {
@@ -35,22 +35,35 @@ __device__ __forceinline__ void xent_row(const float* z, int K, int label, float
   }
 }
 
+// One image per wave, four images per block: no block barrier after the shared coefficients are
+// in LDS, and a quarter of the workgroups (1024 one-image blocks spent most of the kernel's time
+// being dispatched). Lane l owns channel group l % C4 (64 % C4 == 0) of pixels l / C4, l / C4 + 64 / C4, ...
+constexpr int kHeadImgs = 4;
+
+__device__ __forceinline__ floatx4 group_sum(floatx4 v, int C4) {
+  for (int off = C4; off < 64; off <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], off);
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
-  __shared__ float s_scale[kMaxC], s_shift[kMaxC], s_feat[kMaxC], s_logit[kMaxK];
-  __shared__ float s_w[kMaxC * kMaxK / 4], s_part[8][kMaxK + 1];
-  const int n = blockIdx.x;
+  __shared__ float s_scale[kMaxC], s_shift[kMaxC];
+  __shared__ float s_w[kMaxC * kMaxK / 4];
   const int C = a.C, C4 = C >> 2, K = a.K, tid = threadIdx.x;
-  // everything the block will need is requested up front: the activation chunks, the FC weights
-  // (to LDS, when they fit) and the BatchNorm statistics; the block's time is one memory round trip
-  // plus the short dependent chain behind it
-  const floatx4* x4 = reinterpret_cast<const floatx4*>(a.x + (size_t)n * a.HW * C);
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.x * kHeadImgs + wave;
+  const bool live = n < a.B;
   const int n4 = a.HW * C4;
-  constexpr int kPre = 4;
+  const floatx4* x4 = reinterpret_cast<const floatx4*>(a.x + (size_t)(live ? n : 0) * a.HW * C);
+  // the first activation chunks are requested before the coefficient chain
+  constexpr int kPre = 8;
   floatx4 pre[kPre];
 #pragma unroll
   for (int u = 0; u < kPre; ++u) {
-    const int i = tid + 256 * u;
-    pre[u] = i < n4 ? x4[i] : floatx4{0.f, 0.f, 0.f, 0.f};
+    const int i = lane + 64 * u;
+    pre[u] = (live && i < n4) ? x4[i] : floatx4{0.f, 0.f, 0.f, 0.f};
   }
   const bool w_in_lds = C * K <= kMaxC * kMaxK / 4;
   if (w_in_lds)
@@ -59,122 +72,132 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
   for (int c = tid; c < C; c += 256) {
     float m, r;
     bn_coeffs(a.bn, c, C, s_scale[c], s_shift[c], m, r);
-    s_feat[c] = 0.f;
   }
   __syncthreads();
-  // 256 % C4 == 0 is guaranteed by the launcher, so each thread keeps one channel group.
-  const int c = (tid % C4) * 4;
-  floatx4 s = {0, 0, 0, 0};
+  if (!live) return;
+
+  const int g = lane % C4, c = 4 * g;
+  floatx4 sc, sh;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { sc[e] = s_scale[c + e]; sh[e] = s_shift[c + e]; }
+  floatx4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < kPre; ++u) {
-    if (tid + 256 * u < n4) {
+    if (lane + 64 * u < n4) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s[e] += fmaxf(pre[u][e] * s_scale[c + e] + s_shift[c + e], 0.f);
+      for (int e = 0; e < 4; ++e) s[e] += fmaxf(pre[u][e] * sc[e] + sh[e], 0.f);
     }
   }
-  for (int i = tid + 256 * kPre; i < n4; i += 256) {
+  for (int i = lane + 64 * kPre; i < n4; i += 64) {
     const floatx4 v = x4[i];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s[e] += fmaxf(v[e] * s_scale[c + e] + s_shift[c + e], 0.f);
+    for (int e = 0; e < 4; ++e) s[e] += fmaxf(v[e] * sc[e] + sh[e], 0.f);
   }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) atomicAdd(&s_feat[c + e], s[e]);
-  __syncthreads();
+  s = group_sum(s, C4);   // every lane of group g now holds the group's four channel sums
   const float inv_hw = 1.f / (float)a.HW;
-  for (int cc = tid; cc < C; cc += 256) {
-    const float f = s_feat[cc] * inv_hw;
-    s_feat[cc] = f;
-    a.feat[(size_t)n * C + cc] = f;
-  }
-  __syncthreads();
-  // logits: thread (part, k) sums every 8th channel, 8 partial sums per class
-  {
-    const int k = tid & 31, part = tid >> 5;   // 8 parts x 32 class slots
-    float z = 0.f;
-    if (k < K)
-      for (int cc = part; cc < C; cc += 8) z += s_feat[cc] * fw[cc * K + k];
-    if (k < K) s_part[part][k] = z;
-  }
-  __syncthreads();
-  if (tid < K) {
-    float z = a.fc_b[tid];
 #pragma unroll
-    for (int part = 0; part < 8; ++part) z += s_part[part][tid];
-    s_logit[tid] = z;
-    a.logits[(size_t)n * K + tid] = z;
-  }
-  __syncthreads();
-  if (tid < 64) {
-    // softmax cross-entropy of the row by one wave, lane = class (K <= 32)
-    const int label = a.labels[n];
-    const float z = tid < K ? s_logit[tid] : -3.0e38f;
-    float mx = z;
+  for (int e = 0; e < 4; ++e) s[e] *= inv_hw;
+  if (lane < C4) *reinterpret_cast<floatx4*>(a.feat + (size_t)n * C + c) = s;
+
+  // logits: lane (k = lane % 32, half = lane / 32) sums the channel groups of its half
+  const int k = lane & 31, half = lane >> 5;
+  float z = 0.f;
+  for (int gg = half; gg < C4; gg += 2) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    const float e = tid < K ? __expf(z - mx) : 0.f;
-    const float se = wave_sum(e);
-    const float zl = __shfl(z, label);
-    if (tid < K) a.dlogits[(size_t)n * K + tid] = (e / se - (tid == label ? 1.f : 0.f)) / (float)a.B;
-    const unsigned long long at_max = __ballot(tid < K && z == mx);
-    if (tid == 0) {
-      const int slot = n & (a.slots - 1);
-      atomicAdd(a.loss + slot, (mx + __logf(se) - zl) / (float)a.B);
-      if (a.correct && (__ffsll((long long)at_max) - 1) == label) atomicAdd(a.correct + slot, 1);   // first maximum wins, as argmax does
+    for (int e = 0; e < 4; ++e) {
+      const float f = __shfl(s[e], gg);   // lane gg belongs to group gg
+      if (k < K) z += f * fw[(4 * gg + e) * K + k];
     }
+  }
+  z += __shfl_xor(z, 32);
+  if (k < K) z += a.fc_b[k];
+  if (lane < K) a.logits[(size_t)n * K + lane] = z;
+
+  // softmax cross-entropy of the row, lane = class (K <= 32; lanes 32.. mirror lanes 0..31)
+  const int label = a.labels[n];
+  const float zz = k < K ? z : -3.0e38f;
+  float mx = zz;
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  const float ex = (lane < K) ? __expf(zz - mx) : 0.f;
+  const float se = wave_sum(ex);
+  const float zl = __shfl(zz, label);
+  if (lane < K) a.dlogits[(size_t)n * K + lane] = (ex / se - (lane == label ? 1.f : 0.f)) / (float)a.B;
+  const unsigned long long at_max = __ballot(lane < K && zz == mx);
+  if (lane == 0) {
+    const int slot = n & (a.slots - 1);
+    atomicAdd(a.loss + slot, (mx + __logf(se) - zl) / (float)a.B);
+    if (a.correct && (__ffsll((long long)at_max) - 1) == label) atomicAdd(a.correct + slot, 1);   // first maximum wins, as argmax does
   }
 }
 
 __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
-  __shared__ float s_scale[kMaxC], s_shift[kMaxC], s_mean[kMaxC], s_rstd[kMaxC], s_df[kMaxC];
+  __shared__ float s_scale[kMaxC], s_shift[kMaxC], s_mean[kMaxC], s_rstd[kMaxC];
+  __shared__ float s_w[kMaxC * kMaxK / 4];
   __shared__ float s_red[2 * kMaxC];
-  __shared__ float s_dz[kMaxK];
-  const int n = blockIdx.x;
   const int C = a.C, C4 = C >> 2, K = a.K, tid = threadIdx.x;
-  // the activation chunks are requested before the short dependent chain of coefficients
-  const floatx4* x4 = reinterpret_cast<const floatx4*>(a.x + (size_t)n * a.HW * C);
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.x * kHeadImgs + wave;
+  const bool live = n < a.B;
   const int n4 = a.HW * C4;
-  constexpr int kPre = 4;
+  const floatx4* x4 = reinterpret_cast<const floatx4*>(a.x + (size_t)(live ? n : 0) * a.HW * C);
+  constexpr int kPre = 8;
   floatx4 pre[kPre];
 #pragma unroll
   for (int u = 0; u < kPre; ++u) {
-    const int i = tid + 256 * u;
-    pre[u] = i < n4 ? x4[i] : floatx4{0.f, 0.f, 0.f, 0.f};
+    const int i = lane + 64 * u;
+    pre[u] = (live && i < n4) ? x4[i] : floatx4{0.f, 0.f, 0.f, 0.f};
   }
-  if (tid < K) s_dz[tid] = a.dlogits[(size_t)n * K + tid];
+  const float dz_lane = (live && lane < K) ? a.dlogits[(size_t)n * K + lane] : 0.f;
+  const bool w_in_lds = C * K <= kMaxC * kMaxK / 4;
+  if (w_in_lds)
+    for (int e = tid; e < C * K; e += 256) s_w[e] = a.fc_w[e];
+  const float* fw = w_in_lds ? s_w : a.fc_w;
   for (int c = tid; c < C; c += 256) {
     bn_coeffs(a.bn, c, C, s_scale[c], s_shift[c], s_mean[c], s_rstd[c]);
     s_red[c] = 0.f;
     s_red[C + c] = 0.f;
   }
   __syncthreads();
-  const float inv_hw = 1.f / (float)a.HW;
-  for (int c = tid; c < C; c += 256) {
-    float d = 0.f;
-    for (int k = 0; k < K; ++k) d += s_dz[k] * a.fc_w[c * K + k];
-    s_df[c] = d * inv_hw;
-  }
-  __syncthreads();
-  floatx4* g4 = reinterpret_cast<floatx4*>(a.g + (size_t)n * a.HW * C);
-  const int c = (tid % C4) * 4;
-  floatx4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
-  auto one = [&](int i, const floatx4& x) {
-    floatx4 g;
+  if (live) {
+    const int g = lane % C4, c = 4 * g;
+    floatx4 sc, sh, mean, rstd, df = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      g[e] = (x[e] * s_scale[c + e] + s_shift[c + e] > 0.f) ? s_df[c + e] : 0.f;
-      s1[e] += g[e];
-      s2[e] += g[e] * ((x[e] - s_mean[c + e]) * s_rstd[c + e]);
+    for (int e = 0; e < 4; ++e) { sc[e] = s_scale[c + e]; sh[e] = s_shift[c + e]; mean[e] = s_mean[c + e]; rstd[e] = s_rstd[c + e]; }
+    // gradient of the pooled feature: d feat[c] = sum_k dz[k] w[c][k], spread over the HW pixels
+    for (int k = 0; k < K; ++k) {
+      const float dzk = __shfl(dz_lane, k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) df[e] += dzk * fw[(c + e) * K + k];
     }
-    g4[i] = g;
-  };
+    const float inv_hw = 1.f / (float)a.HW;
 #pragma unroll
-  for (int u = 0; u < kPre; ++u)
-    if (tid + 256 * u < n4) one(tid + 256 * u, pre[u]);
-  for (int i = tid + 256 * kPre; i < n4; i += 256) one(i, x4[i]);
+    for (int e = 0; e < 4; ++e) df[e] *= inv_hw;
+    floatx4* g4 = reinterpret_cast<floatx4*>(a.g + (size_t)n * a.HW * C);
+    floatx4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    auto one = [&](int i, const floatx4& x) {
+      floatx4 gv;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    atomicAdd(&s_red[c + e], s1[e]);
-    atomicAdd(&s_red[C + c + e], s2[e]);
+      for (int e = 0; e < 4; ++e) {
+        gv[e] = (x[e] * sc[e] + sh[e] > 0.f) ? df[e] : 0.f;
+        s1[e] += gv[e];
+        s2[e] += gv[e] * ((x[e] - mean[e]) * rstd[e]);
+      }
+      g4[i] = gv;
+    };
+#pragma unroll
+    for (int u = 0; u < kPre; ++u)
+      if (lane + 64 * u < n4) one(lane + 64 * u, pre[u]);
+    for (int i = lane + 64 * kPre; i < n4; i += 64) one(i, x4[i]);
+    s1 = group_sum(s1, C4);
+    s2 = group_sum(s2, C4);
+    if (lane < C4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        atomicAdd(&s_red[c + e], s1[e]);
+        atomicAdd(&s_red[C + c + e], s2[e]);
+      }
+    }
   }
   __syncthreads();
   double* slot = stat_slot(a.gsums, C);
@@ -241,16 +264,16 @@ __global__ __launch_bounds__(256) void top1_kernel(Top1Args a) {
 }  // namespace
 
 void head_fwd(const HeadFwdArgs& a, hipStream_t stream) {
-  if (a.K > kMaxK || a.C > kMaxC || (a.C & 3) || (256 % (a.C / 4)) != 0)
+  if (a.K > kMaxK || a.C > kMaxC || (a.C & 3) || (64 % (a.C / 4)) != 0)
     throw std::runtime_error("head_fwd: unsupported C/K");
   if (a.slots < 1 || (a.slots & (a.slots - 1))) throw std::runtime_error("head_fwd: slots must be a power of two");
-  launch("head_fwd", head_fwd_kernel, dim3(a.B), dim3(256), 0, stream, a);
+  launch("head_fwd", head_fwd_kernel, dim3(ceil_div(a.B, kHeadImgs)), dim3(256), 0, stream, a);
 }
 
 void head_bwd(const HeadBwdArgs& a, hipStream_t stream) {
-  if (a.K > kMaxK || a.C > kMaxC || (a.C & 3) || (256 % (a.C / 4)) != 0)
+  if (a.K > kMaxK || a.C > kMaxC || (a.C & 3) || (64 % (a.C / 4)) != 0)
     throw std::runtime_error("head_bwd: unsupported C/K");
-  launch("head_bwd", head_bwd_kernel, dim3(a.B), dim3(256), 0, stream, a);
+  launch("head_bwd", head_bwd_kernel, dim3(ceil_div(a.B, kHeadImgs)), dim3(256), 0, stream, a);
   // ~16 samples per thread: the loop is a chain of dependent loads, so depth, not atomics, sets its time
   int splits = a.B / 16;
   if (splits < 1) splits = 1;
