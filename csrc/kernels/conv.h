@@ -130,6 +130,11 @@ struct ConvBwdFusedArgs {
   const double* dy_gsums;  // [kStatSlots][2*C]
   float* dy_dgamma;        // [C], nullable
   float* dy_dbeta;         // [C], nullable
+  // With the prologue, optionally dy_eff += dy_res (the gradient arriving over an identity
+  // shortcut) and dy_eff is written to dy_out: the residual block's input gradient, which the
+  // block before needs again, is produced here instead of by a separate elementwise pass.
+  const float* dy_res;     // [B,H,W,C], nullable
+  float* dy_out;           // [B,H,W,C], required with dy_res
   // Optional dynamic tile scheduling: kBwdTileCounters zeroed ints. A block takes its first two
   // bands statically and every further one from the counter of its XCD (and channel split), so
   // when some CUs are shared with another kernel (an all-reduce of an earlier gradient bucket, a

@@ -20,7 +20,10 @@
 // Blocks are persistent over bands (register prefetch of the next band); the ci dimension may be
 // split over blocks (zsplit): a block then owns rows [ci slice] of dW and the same channels of g.
 // With the optional prologue (ConvBwdFusedArgs::dy_x) the BatchNorm backward of the FOLLOWING
-// layer is applied to dy while it is staged, so that tensor is never materialised either. Filter gradients are flushed once per block through LDS into the gradient
+// layer is applied to dy while it is staged, so that tensor is never materialised either; with
+// dy_res / dy_out the gradient of an identity shortcut is added and the sum written out once (the
+// 32-channel instance has the registers for the third prefetched tensor; the 16- and 64-channel
+// ones spill 34 / 16 registers and are slower than the separate elementwise pass they replace). Filter gradients are flushed once per block through LDS into the gradient
 // copy of the block's XCD; statistics go to per-XCD slots.
 // (reference ops: conv2d_backprop_input + conv2d_backprop_filter + the BatchNorm / ReLU gradients
 //  under opt.compute_gradients, DistributedResNet/src/distributed_train.py:256)
@@ -67,8 +70,9 @@ struct BF {
   static_assert(TW % 8 == 0 && (TH * TW) % 16 == 0, "k-steps are taken from 16-pixel segments of whole rows");
 };
 
-template <int C, int NT, int TW, int TH, bool DYBN>
+template <int C, int NT, int TW, int TH, bool DYBN, bool RES = false>
 __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs a) {
+  static_assert(!RES || DYBN, "the shortcut term rides on the BatchNorm prologue");
   using G = BF<C, NT, TW, TH>;
   constexpr int CPP = G::CPP, XC = G::XC, XPP = G::XPP, CG = G::CG, KG = G::KG, LW = G::LW;
   constexpr int MTW = G::MTW, ITER = G::ITER, CO_T = G::CO_T, WP = G::WP, WX = G::WX;
@@ -150,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
 
   floatx4 pf_d[G::NPF_D], pf_x[G::NPF_X];
   floatx4 pf_c[DYBN ? G::NPF_D : 1];
+  floatx4 pf_r[RES ? G::NPF_D : 1];
   unsigned okbits = 0;
   auto load_band = [&](int t) {
     const int n = t / bands;
@@ -179,7 +184,17 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
       pf_x[k] = v;
     }
   };
-  auto write_band = [&]() {
+  // The shortcut term of the next band is requested between the two MFMA phases: by then the data
+  // gradient's registers are free, and the filter-gradient phase covers the latency.
+  auto load_res = [&](int t) {
+    const int n = t / bands;
+    const int oy0 = (t - n * bands) * TH;
+    const float* r0 = a.dy_res + ((long long)(n * a.H + oy0 - 1) * a.W) * C;
+#pragma unroll
+    for (int k = 0; k < G::NPF_D; ++k)
+      if ((okbits >> k) & 1u) pf_r[k] = *reinterpret_cast<const floatx4*>(r0 + d_goff[k]);
+  };
+  auto write_band = [&](long long doff) {
 #pragma unroll
     for (int k = 0; k < G::NPF_D; ++k)
       if (tid + k * 256 < G::D_CHUNKS) {
@@ -192,6 +207,12 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
           const floatx4 cc = *reinterpret_cast<const floatx4*>(s_dco + 2 * C + ch);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = ca[e] * v[e] + (cb[e] * pf_c[k][e] + cc[e]);
+          if (RES) {
+            v += pf_r[k];
+            // the band's own rows (not the halo) of this block's channel slice leave as the block input gradient
+            const int row = (d_lr[k] >> 16) - 1;
+            if (row >= 1 && row <= TH && (unsigned)(ch - c0) < (unsigned)XC) *reinterpret_cast<floatx4*>(a.dy_out + doff + d_goff[k]) = v;
+          }
         }
         *reinterpret_cast<floatx4*>(s_dy + (d_lr[k] & 0xffff)) = v;
       }
@@ -214,7 +235,10 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
   int t_next = t + gpz;
   int r_fetch = total_tiles;        // thread 0: the tile after t_next
   if (ctr && tid == 0) r_fetch = take_tile();
-  if (t < total_tiles) load_band(t);
+  if (t < total_tiles) {
+    load_band(t);
+    if (RES) load_res(t);
+  }
 
   if (co_thread) {
     const double mean = s1 * (double)a.bn.inv_count;
@@ -287,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
     const int oy0 = (t - n * bands) * TH;
     const long long obase = ((long long)(n * a.H + oy0) * TW) * C;
 
-    write_band();
+    write_band(((long long)(n * a.H + oy0 - 1) * a.W) * C);
     if (ctr && tid == 0) s_next_tile = r_fetch;
     __syncthreads();
     const int t_after = ctr ? s_next_tile : t_next + gpz;
@@ -356,6 +380,8 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
       }
     }
 
+    if (RES && t_next < total_tiles) load_res(t_next);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- filter gradient: M = ci, N = co, K = pixels of the band ---------------------------------------
     {
       float af0, bf0[9], af1, bf1[9];
@@ -404,16 +430,16 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
   }
 }
 
-template <int C, int NT, int TW, int TH, bool DYBN>
+template <int C, int NT, int TW, int TH, bool DYBN, bool RES = false>
 size_t launch_bf(const ConvBwdFusedArgs& a, hipStream_t stream) {
   using G = BF<C, NT, TW, TH>;
   const size_t shmem = (size_t)G::LDS_FLOATS * sizeof(float);
   constexpr int zsplit = (C / 16) / NT;
   const int total_tiles = (a.H / TH) * a.B;
   static const int bpc = [&] {
-    ensure_dynamic_lds(reinterpret_cast<const void*>(conv_bwd_fused_kernel<C, NT, TW, TH, DYBN>), shmem);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(conv_bwd_fused_kernel<C, NT, TW, TH, DYBN, RES>), shmem);
     int n = 0;
-    DTF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_bwd_fused_kernel<C, NT, TW, TH, DYBN>, 256, shmem));
+    DTF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_bwd_fused_kernel<C, NT, TW, TH, DYBN, RES>, 256, shmem));
     return n < 1 ? 1 : n;
   }();
   int gpz_max = (256 * bpc) / zsplit;
@@ -425,7 +451,7 @@ size_t launch_bf(const ConvBwdFusedArgs& a, hipStream_t stream) {
   const int iters = ceil_div(total_tiles, gpz_max);
   int gpz = ceil_div(total_tiles, iters);
   gpz = (gpz + 7) / 8 * 8;
-  launch("conv_bwd_fused", conv_bwd_fused_kernel<C, NT, TW, TH, DYBN>, dim3(gpz * zsplit), dim3(256), shmem, stream, a);
+  launch("conv_bwd_fused", conv_bwd_fused_kernel<C, NT, TW, TH, DYBN, RES>, dim3(gpz * zsplit), dim3(256), shmem, stream, a);
   return shmem;
 }
 
@@ -441,6 +467,12 @@ size_t conv_bwd_fused(const ConvBwdFusedArgs& a, hipStream_t stream) {
   if (!a.dy || !a.x || !a.wpk_t || !a.g || !a.dw || !a.bn.sums) throw std::runtime_error("conv_bwd_fused: null operand");
   if (a.dy_x) {
     if (!a.dy_bn.sums || !a.dy_gsums) throw std::runtime_error("conv_bwd_fused: the BatchNorm prologue needs its statistics");
+    if (a.dy_res) {
+      if (!a.dy_out) throw std::runtime_error("conv_bwd_fused: dy_res needs dy_out");
+      if (a.C == 16) return launch_bf<16, 1, 32, 8, true, true>(a, stream);
+      if (a.C == 32) return launch_bf<32, 1, 16, 8, true, true>(a, stream);
+      return launch_bf<64, 1, 8, 8, true, true>(a, stream);
+    }
     if (a.C == 16) return launch_bf<16, 1, 32, 8, true>(a, stream);
     if (a.C == 32) return launch_bf<32, 1, 16, 8, true>(a, stream);
     return launch_bf<64, 1, 8, 8, true>(a, stream);

@@ -147,6 +147,7 @@ class ResNetHipStep(StepProgramBase):
             self.dynamic_tiles = os.environ.get("DTF_DYNAMIC_TILES", "0") != "0"
             self._tile_ctr = torch.zeros(2 * len(self.blocks) * nv.hip().BWD_TILE_COUNTERS, device=dev, dtype=torch.int32)
             self._tile_ctr_used = 0
+            self._g_raw = {}
             # With separate filter-gradient kernels a side stream hides them behind the data-gradient
             # chain (1.40 -> 1.24 ms/step at batch 256); with the fused kernels only three filter
             # gradients remain and the second stream measures slightly slower (1.23 vs 1.19 ms).
@@ -265,24 +266,27 @@ class ResNetHipStep(StepProgramBase):
         def fusable(x, conv):
             return self.fused_backward and conv.stride == 1 and conv.cin == conv.cout and nv.conv_bwd_fused_supported(x)
 
-        def layer_backward(x, dout, conv, bn, out, extra=None, dout_bn=None):
+        def layer_backward(x, dout, conv, bn, out, extra=None, dout_bn=None, shortcut=None):
             """Gradient at the BatchNorm output of the layer's input (masked, with the BN-backward
             sums) and the layer's filter gradient. dout_bn = (y, _Bn): `dout` is the masked gradient
             at the output of the BatchNorm after this convolution and that BatchNorm's backward
-            is applied on the fly (fused kernel only)."""
+            is applied on the fly (fused kernel only); shortcut = (res, dy_out) adds the gradient of
+            an identity shortcut to it and writes the sum to dy_out."""
             s = conv.stride
             if fusable(x, conv):
                 kw = {}
                 if dout_bn is not None:
                     y_t, ybn = dout_bn
                     kw = dict(dy_bn=(y_t, ybn.fwd, ybn.gsums), dy_dgamma=a.grad(ybn.gamma_name), dy_dbeta=a.grad(ybn.beta_name))
+                    if shortcut is not None:
+                        kw.update(dy_res=shortcut[0], dy_out=shortcut[1])
                 if self.dynamic_tiles:
                     nctr = nv.hip().BWD_TILE_COUNTERS
                     kw["tile_counters"] = self._tile_ctr[self._tile_ctr_used:self._tile_ctr_used + nctr]
                     self._tile_ctr_used += nctr
                 return nv.conv_bwd_fused(dout, x, bn.fwd, self._wpk(conv.weight, True), dw_slot_view(conv.weight), bn.gsums,
                                          slot_stride=a.total, extra=extra, out=out, **kw)
-            assert dout_bn is None
+            assert dout_bn is None and shortcut is None
             wgrad(x, dout, conv.weight, s, bn.fwd)
             _, pb, _ = same_pad(x.shape[1], 3, s)
             return nv.conv_fprop(dout, self._wpk(conv.weight, True), ks=3, cout=conv.cin, stride=1, upsample=(s == 2),
@@ -301,6 +305,24 @@ class ResNetHipStep(StepProgramBase):
         nv.head_bwd(x_last, self.bnf.fwd, a.param("fc/fc_weights"), self.feat, self.dlogits, dy, self.bnf.gsums,
                     a.grad("fc/fc_weights"), a.grad("fc/fc_bias"))
         nv.bn_bwd_apply(dy, x_last, self.bnf.fwd, self.bnf.gsums, dgamma=a.grad("fc/gamma"), dbeta=a.grad("fc/beta"), out=dy)
+        # An identity block's last step, d(block input) = BN1-backward(g1) + d(block output), is
+        # folded into the convolution that consumes it (conv2 of the block before) for the channel
+        # counts in DTF_BWD_SHORTCUT_FUSE: that kernel stages the sum from its three operands and
+        # writes it out for the shortcut of the block before. Measured at batch 1024: 32 channels
+        # 110 -> 102 us per block; 16 channels 134 -> 162 us (the kernel spills), 64 channels no gain,
+        # hence the default. Not across a bucket boundary: BN1's dgamma / dbeta would be written
+        # after their bucket has left.
+        fuse_c = {int(v) for v in os.environ.get("DTF_BWD_SHORTCUT_FUSE", "32").split(",") if v.strip()}
+
+        def folds_into_previous(k):
+            if k == 0 or k in marks or not self.fused_backward:
+                return False
+            blk, prev = blocks[k], blocks[k - 1]
+            if blk.first_block or blk.increase_dim or blk.conv1.cin not in fuse_c:
+                return False
+            return fusable(self.y[k - 1], blk.conv1) and fusable(self.c1[k - 1], prev.conv2)
+
+        pending = None   # (raw g1 of the block after, its input, its BN1, its output gradient)
         for k in range(len(blocks) - 1, -1, -1):
             blk = blocks[k]
             x_in = self.c0 if k == 0 else self.y[k - 1]
@@ -309,8 +331,20 @@ class ResNetHipStep(StepProgramBase):
             c1 = self.c1[k]
             dy = self._d_out[k]
             # conv2: filter gradient + masked data gradient, then BN backward
-            g2 = layer_backward(c1, dy, blk.conv2, bn2, self._d_c1[k])
-            g1_out = self._d_c0 if k == 0 else self._d_out[k - 1]
+            if pending is not None:
+                g_raw, nx_in, nbn1, ndy = pending
+                g2 = layer_backward(c1, g_raw, blk.conv2, bn2, self._d_c1[k], dout_bn=(nx_in, nbn1), shortcut=(ndy, dy))
+                pending = None
+            else:
+                g2 = layer_backward(c1, dy, blk.conv2, bn2, self._d_c1[k])
+            fold = folds_into_previous(k)
+            if fold:
+                key = tuple(x_in.shape)
+                if key not in self._g_raw:
+                    self._g_raw[key] = torch.empty_like(x_in)
+                g1_out = self._g_raw[key]
+            else:
+                g1_out = self._d_c0 if k == 0 else self._d_out[k - 1]
             if fusable(x_in, blk.conv1):
                 # conv1's fused backward applies BN2's backward while it stages g2: dc1 is never written
                 g1 = layer_backward(x_in, g2, blk.conv1, bn1, g1_out, extra=dy if blk.first_block else None,
@@ -319,14 +353,17 @@ class ResNetHipStep(StepProgramBase):
                 dc1 = nv.bn_bwd_apply(g2, c1, bn2.fwd, bn2.gsums, dgamma=a.grad(bn2.gamma_name), dbeta=a.grad(bn2.beta_name),
                                       out=g2)
                 g1 = layer_backward(x_in, dc1, blk.conv1, bn1, g1_out, extra=dy if blk.first_block else None)
-            if blk.first_block:
-                res = dict(res_mode=nv.BWD_RES_NONE)
-            elif blk.increase_dim:
-                res = dict(res_mode=nv.BWD_RES_SHORTCUT_A, res=dy)
+            if fold:
+                pending = (g1, x_in, bn1, dy)
             else:
-                res = dict(res_mode=nv.BWD_RES_IDENT, res=dy)
-            nv.bn_bwd_apply(g1, x_in, bn1.fwd, bn1.gsums, dgamma=a.grad(bn1.gamma_name), dbeta=a.grad(bn1.beta_name),
-                            out=g1, **res)
+                if blk.first_block:
+                    res = dict(res_mode=nv.BWD_RES_NONE)
+                elif blk.increase_dim:
+                    res = dict(res_mode=nv.BWD_RES_SHORTCUT_A, res=dy)
+                else:
+                    res = dict(res_mode=nv.BWD_RES_IDENT, res=dy)
+                nv.bn_bwd_apply(g1, x_in, bn1.fwd, bn1.gsums, dgamma=a.grad(bn1.gamma_name), dbeta=a.grad(bn1.beta_name),
+                                out=g1, **res)
             if k in marks:
                 end_bucket(marks[k], hi)
                 hi = marks[k]

@@ -445,14 +445,16 @@ def conv_bwd_fused_supported(x: torch.Tensor) -> bool:
 
 
 def conv_bwd_fused(dy, x, bn: BnState, wpk_t, dw, gsums, *, slot_stride: int = 0, extra=None, out=None,
-                   dy_bn=None, dy_dgamma=None, dy_dbeta=None, tile_counters=None):
+                   dy_bn=None, dy_dgamma=None, dy_dbeta=None, dy_res=None, dy_out=None, tile_counters=None):
     """Backward of y = conv3x3(relu(bn(x)), W), stride 1, in one kernel: returns the masked data
     gradient g, adds (sum g, sum g*xhat) to `gsums` and the filter gradient to `dw`
     (see csrc/kernels/conv.h: ConvBwdFusedArgs).
 
     dy_bn = (y, BnState of y, backward sums of that BatchNorm): `dy` is then the masked gradient
     at the output of the BatchNorm that follows the convolution, and the BatchNorm input gradient
-    is formed on the fly; dy_dgamma / dy_dbeta receive that BatchNorm's parameter gradients."""
+    is formed on the fly; dy_dgamma / dy_dbeta receive that BatchNorm's parameter gradients.
+    With dy_res / dy_out (and dy_bn) the gradient of an identity shortcut is added to that
+    BatchNorm input gradient and the sum is written to dy_out (a buffer other than dy)."""
     require()
     b, h, w_, c = x.shape
     if tuple(dy.shape) != (b, h, w_, c) or tuple(dw.shape) != (3, 3, c, c) or bn.channels != c:
@@ -485,6 +487,15 @@ def conv_bwd_fused(dy, x, bn: BnState, wpk_t, dw, gsums, *, slot_stride: int = 0
                 if t.numel() != c:
                     raise ValueError(f"{key} must have C elements")
                 d[key] = _chk(t, key)
+    if (dy_res is None) != (dy_out is None) or (dy_res is not None and dy_bn is None):
+        raise ValueError("conv_bwd_fused: dy_res, dy_out and dy_bn go together")
+    if dy_res is not None:
+        if tuple(dy_res.shape) != (b, h, w_, c) or tuple(dy_out.shape) != (b, h, w_, c):
+            raise ValueError("conv_bwd_fused: dy_res / dy_out have the wrong shape")
+        if dy_out.data_ptr() in (dy.data_ptr(), dy_res.data_ptr(), x.data_ptr(), out.data_ptr()):
+            raise ValueError("conv_bwd_fused: dy_out must not alias an operand (other bands still read their halo rows)")
+        d["dy_res"] = _chk(dy_res, "dy_res")
+        d["dy_out"] = _chk(dy_out, "dy_out")
     if tile_counters is not None:
         # zeroed int32 block: bands are handed out dynamically (robust when CUs are shared with a collective)
         if tile_counters.dtype != torch.int32 or tile_counters.numel() < hip().BWD_TILE_COUNTERS:

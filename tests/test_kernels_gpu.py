@@ -368,6 +368,48 @@ def test_conv_bwd_fused_with_bn_backward_prologue(shape):
     close(dbet, db2, 1e-4)
 
 
+@pytest.mark.parametrize("shape", [(5, 32, 16), (6, 16, 32), (9, 8, 64), (300, 32, 16), (260, 16, 32)])
+def test_conv_bwd_fused_prologue_with_shortcut_gradient(shape):
+    # as above, and y also feeds an identity shortcut whose gradient `res` arrives from the block
+    # after: the kernel stages dy = bn2_backward(du2) + res and writes it out as the block input gradient
+    b, h, c = shape
+    x = rnd(b, h, h, c, scale=1.5) + 0.1
+    g1, b1 = rnd(c).abs() + 0.5, rnd(c, scale=0.3)
+    g2 = (rnd(c, seed=61).abs() + 0.5).requires_grad_(True)
+    b2 = rnd(c, scale=0.3, seed=62).requires_grad_(True)
+    w1 = rnd(3, 3, c, c, scale=0.1).requires_grad_(True)
+    w2 = rnd(3, 3, c, c, scale=0.1, seed=63)
+    a1 = torch.relu(ref.batch_norm(x, g1, b1)).requires_grad_(True)
+    y = ref.conv2d_same(a1, w1, 1)
+    y.retain_grad()
+    u2 = ref.batch_norm(y, g2, b2)
+    z = ref.conv2d_same(torch.relu(u2), w2, 1)
+    dz = rnd(*z.shape, seed=64)
+    res = rnd(*y.shape, seed=65)
+    loss = (z * dz).sum() + (y * res).sum()
+    da1, dw1, dg2, db2, dy_total = torch.autograd.grad(loss, (a1, w1, g2, b2, y), retain_graph=True)
+    (du2,) = torch.autograd.grad((z * dz).sum(), u2)
+    want_g = torch.where(ref.batch_norm(x, g1, b1) > 0, da1, torch.zeros_like(da1))
+    yd = y.detach()
+    mean, var = ref.batch_moments(yd)
+    yhat = (yd - mean) * torch.rsqrt(var + ref.BN_EPSILON)
+    gs2 = nv.stats_from_totals(torch.cat([du2.reshape(-1, c).double().sum(0), (du2 * yhat).reshape(-1, c).double().sum(0)]))
+    n = dw1.numel()
+    slots = torch.zeros(nv.STAT_SLOTS, n, device=DEV)
+    gs1 = nv.new_stats(c, DEV)
+    dgam, dbet = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    dy_out = torch.full_like(yd, 7.0)
+    got = nv.conv_bwd_fused(du2.contiguous(), x, bn_state_for(x, g1, b1), nv.pack_weights(w1.detach(), flip=True),
+                            slots[0].view(3, 3, c, c), gs1, slot_stride=n,
+                            dy_bn=(yd, bn_state_for(yd, g2.detach(), b2.detach()), gs2), dy_dgamma=dgam, dy_dbeta=dbet,
+                            dy_res=res, dy_out=dy_out)
+    close(dy_out, dy_total, 2e-4)
+    close(got, want_g, 2e-4)
+    close(slots.sum(0).view(dw1.shape), dw1, 2e-4)
+    close(dgam, dg2, 1e-4)
+    close(dbet, db2, 1e-4)
+
+
 def test_conv_dgrad_mask_epilogue():
     b, h, w, cin, cout = 4, 16, 16, 32, 32
     x_pre = rnd(b, h, w, cin, scale=1.5)          # BN input of the layer below

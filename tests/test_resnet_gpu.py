@@ -143,10 +143,14 @@ def test_gpu_batcher_matches_host_batcher():
 
 
 @pytest.mark.parametrize("env", [dict(DTF_BWD_FUSED="0", DTF_SIDE_STREAM="1"), dict(DTF_BWD_FUSED="0", DTF_SIDE_STREAM="0"),
-                                 dict(DTF_BWD_FUSED="1", DTF_SIDE_STREAM="1")])
+                                 dict(DTF_BWD_FUSED="1", DTF_SIDE_STREAM="1"),
+                                 dict(DTF_BWD_FUSED="1", DTF_SIDE_STREAM="0", DTF_BWD_SHORTCUT_FUSE=""),
+                                 dict(DTF_BWD_FUSED="1", DTF_SIDE_STREAM="0", DTF_BWD_SHORTCUT_FUSE="16,32,64")])
 def test_backward_variants_agree(monkeypatch, env):
-    """Separate data/filter-gradient kernels (with the filter gradients on a side lane or not) and
-    the fused backward kernels must produce the same gradients and the same update."""
+    """Separate data/filter-gradient kernels (with the filter gradients on a side lane or not), the
+    fused backward kernels, and the fused kernels with the identity blocks' input gradient folded
+    into the consuming convolution (for no / all channel counts; the default is 32 only) must
+    produce the same gradients and the same update."""
     from distributed_tensorflow_amd.models.resnet_hip import ResNetHipStep
 
     b = 16
@@ -159,7 +163,7 @@ def test_backward_variants_agree(monkeypatch, env):
             monkeypatch.setenv(k, v)
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
-            step = ResNetHipStep(2, b, num_buckets=2)
+            step = ResNetHipStep(3, b, num_buckets=2)
             step.load_batch(images, labels)
             step.set_hyper(lr_t=0.0)
             step.run(graph=False)
