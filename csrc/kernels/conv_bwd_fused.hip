@@ -21,9 +21,10 @@
 // split over blocks (zsplit): a block then owns rows [ci slice] of dW and the same channels of g.
 // With the optional prologue (ConvBwdFusedArgs::dy_x) the BatchNorm backward of the FOLLOWING
 // layer is applied to dy while it is staged, so that tensor is never materialised either; with
-// dy_res / dy_out the gradient of an identity shortcut is added and the sum written out once (the
-// 32-channel instance has the registers for the third prefetched tensor; the 16- and 64-channel
-// ones spill 34 / 16 registers and are slower than the separate elementwise pass they replace). Filter gradients are flushed once per block through LDS into the gradient
+// dy_res / dy_out the gradient of an identity shortcut is added and the sum written out once. The
+// third prefetched tensor fits the register file of the 32-channel instance (253 VGPRs); the
+// 16-channel instance runs over 4-row bands for it (212 VGPRs; with 8 rows it spills 34 registers
+// and is slower than the elementwise pass it replaces); the 64-channel instance spills 16. Filter gradients are flushed once per block through LDS into the gradient
 // copy of the block's XCD; statistics go to per-XCD slots.
 // (reference ops: conv2d_backprop_input + conv2d_backprop_filter + the BatchNorm / ReLU gradients
 //  under opt.compute_gradients, DistributedResNet/src/distributed_train.py:256)
@@ -469,7 +470,7 @@ size_t conv_bwd_fused(const ConvBwdFusedArgs& a, hipStream_t stream) {
     if (!a.dy_bn.sums || !a.dy_gsums) throw std::runtime_error("conv_bwd_fused: the BatchNorm prologue needs its statistics");
     if (a.dy_res) {
       if (!a.dy_out) throw std::runtime_error("conv_bwd_fused: dy_res needs dy_out");
-      if (a.C == 16) return launch_bf<16, 1, 32, 8, true, true>(a, stream);
+      if (a.C == 16) return launch_bf<16, 1, 32, 4, true, true>(a, stream);
       if (a.C == 32) return launch_bf<32, 1, 16, 8, true, true>(a, stream);
       return launch_bf<64, 1, 8, 8, true, true>(a, stream);
     }

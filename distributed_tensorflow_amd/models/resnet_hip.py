@@ -308,11 +308,12 @@ class ResNetHipStep(StepProgramBase):
         # An identity block's last step, d(block input) = BN1-backward(g1) + d(block output), is
         # folded into the convolution that consumes it (conv2 of the block before) for the channel
         # counts in DTF_BWD_SHORTCUT_FUSE: that kernel stages the sum from its three operands and
-        # writes it out for the shortcut of the block before. Measured at batch 1024: 32 channels
-        # 110 -> 102 us per block; 16 channels 134 -> 162 us (the kernel spills), 64 channels no gain,
-        # hence the default. Not across a bucket boundary: BN1's dgamma / dbeta would be written
-        # after their bucket has left.
-        fuse_c = {int(v) for v in os.environ.get("DTF_BWD_SHORTCUT_FUSE", "32").split(",") if v.strip()}
+        # writes it out for the shortcut of the block before. Measured at batch 1024, per block:
+        # 32 channels 110 -> 102 us, 16 channels 135 -> 112 us (with 4-row bands, the 8-row instance
+        # spills); the 64-channel instance spills and the pass it replaces takes only 13 us, hence the
+        # default. Not across a bucket boundary: BN1's dgamma / dbeta would be written after their
+        # bucket has left.
+        fuse_c = {int(v) for v in os.environ.get("DTF_BWD_SHORTCUT_FUSE", "16,32").split(",") if v.strip()}
 
         def folds_into_previous(k):
             if k == 0 or k in marks or not self.fused_backward:
