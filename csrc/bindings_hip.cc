@@ -107,6 +107,7 @@ PYBIND11_MODULE(_hip, m) {
   m.def("conv_stem_wgrad", [](const py::dict& d, uint64_t stream) {
     ConvStemArgs a{};
     P(x, const float); P(dy, const float); P(dw, float); V(slot_stride); V(B);
+    P(dy_x, const float); a.dy_bn = as_bn(d, "dy_bn"); P(dy_gsums, const double); P(dy_dgamma, float); P(dy_dbeta, float);
     conv_stem_wgrad(a, as_stream(stream));
   });
   m.def("conv_stem_supported", &conv_stem_supported);

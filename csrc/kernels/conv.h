@@ -159,6 +159,15 @@ struct ConvStemArgs {
   float* dw;         // [27][16], gradient
   int slot_stride;
   int B;
+  // Optional BatchNorm-backward prologue of the gradient kernel (as ConvBwdFusedArgs::dy_x): `dy`
+  // is the masked gradient at the output of the BatchNorm that follows the stem, `dy_x` the stem
+  // output; the BatchNorm input gradient is formed while dy is staged and never written. Block 0
+  // writes that BatchNorm's dgamma / dbeta.
+  const float* dy_x;       // [B,32,32,16], nullable = no prologue
+  BnRef dy_bn;
+  const double* dy_gsums;  // [kStatSlots][32]
+  float* dy_dgamma;        // [16], nullable
+  float* dy_dbeta;         // [16], nullable
 };
 bool conv_stem_supported(int H, int W, int Cin, int Cout, int ks, int stride);
 void conv_stem_fwd(const ConvStemArgs& a, hipStream_t stream);

@@ -97,12 +97,33 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(ConvStemArgs a) {
 }
 
 // dw[k][co] += sum over pixels x[window element k of the pixel] * dy[pixel][co]
+// DYBN: dy is staged as ca * dy + cb * y + cc per channel (BatchNorm backward of the layer after the stem)
+template <bool DYBN>
 __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(ConvStemArgs a) {
   constexpr int DS = 20;   // dy pixel stride in LDS (16 + 4: four pixels of a k-step start 16 banks apart)
   __shared__ __align__(16) float plane[2][kPlane];
   __shared__ __align__(16) float sdy[2][kTH * kW * DS];
   __shared__ float red[4][2][4][64];
+  __shared__ __align__(16) float s_dco[3][16];
   const int tid = threadIdx.x;
+  if (DYBN && tid < 16) {
+    const double inv = (double)a.dy_bn.inv_count;
+    const double ds1 = stat_total(a.dy_bn.sums, tid, 16), ds2 = stat_total(a.dy_bn.sums, 16 + tid, 16);
+    const double dg1 = stat_total(a.dy_gsums, tid, 16), dg2 = stat_total(a.dy_gsums, 16 + tid, 16);
+    const double mean = ds1 * inv;
+    double var = ds2 * inv - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = rsqrtf((float)var + a.dy_bn.eps);
+    const float k1 = a.dy_bn.gamma[tid] * rstd;
+    const float mg = (float)(dg1 * inv), mgx = (float)(dg2 * inv);
+    s_dco[0][tid] = k1;
+    s_dco[1][tid] = -k1 * mgx * rstd;
+    s_dco[2][tid] = k1 * (mgx * (float)mean * rstd - mg);
+    if (blockIdx.x == 0) {
+      if (a.dy_dbeta) a.dy_dbeta[tid] = (float)dg1;
+      if (a.dy_dgamma) a.dy_dgamma[tid] = (float)dg2;
+    }
+  }
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, n = lane & 15;
   for (int i = tid; i < 2 * kPlane; i += 256) (&plane[0][0])[i] = 0.f;
@@ -114,29 +135,50 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(ConvStemArgs a) {
   // the band's 256 pixels x 16 channels are 1024 contiguous 16-byte chunks, four per thread. The
   // prefetch registers are named scalars on purpose: an array handed to a helper by reference is
   // demoted to LDS by the compiler, which turns the prefetch into a synchronous copy.
-  const float4* dy4 = reinterpret_cast<const float4*>(a.dy) + tid;
+  const floatx4* dy4 = reinterpret_cast<const floatx4*>(a.dy) + tid;
+  const floatx4* yx4 = reinterpret_cast<const floatx4*>(DYBN ? a.dy_x : a.dy) + tid;
 #define STEM_FETCH_DY(t)                                        \
   do {                                                          \
-    const float4* src_ = dy4 + (size_t)(t) * (kTH * kW * 4);    \
-    pd0 = src_[0];                                              \
-    pd1 = src_[256];                                            \
-    pd2 = src_[512];                                            \
-    pd3 = src_[768];                                            \
+    const size_t o_ = (size_t)(t) * (kTH * kW * 4);             \
+    pd0 = dy4[o_];                                              \
+    pd1 = dy4[o_ + 256];                                        \
+    pd2 = dy4[o_ + 512];                                        \
+    pd3 = dy4[o_ + 768];                                        \
+    if (DYBN) {                                                 \
+      pc0 = yx4[o_];                                            \
+      pc1 = yx4[o_ + 256];                                      \
+      pc2 = yx4[o_ + 512];                                      \
+      pc3 = yx4[o_ + 768];                                      \
+    }                                                           \
   } while (0)
-  float4 pf = make_float4(0.f, 0.f, 0.f, 0.f), pd0 = pf, pd1 = pf, pd2 = pf, pd3 = pf;
+  float4 pf = make_float4(0.f, 0.f, 0.f, 0.f);
+  floatx4 pd0 = {0.f, 0.f, 0.f, 0.f}, pd1 = pd0, pd2 = pd0, pd3 = pd0, pc0 = pd0, pc1 = pd0, pc2 = pd0, pc3 = pd0;
   int tile = blockIdx.x;
   if (tile < total_tiles) {
     pf = stem_fetch(a.x, tile, tid);
     STEM_FETCH_DY(tile);
   }
   __syncthreads();
+  // every chunk of a thread carries the same four channels 4 (tid % 4) ..
+  floatx4 ca = {1.f, 1.f, 1.f, 1.f}, cb = {0.f, 0.f, 0.f, 0.f}, cc = cb;
+  if (DYBN) {
+    ca = *reinterpret_cast<const floatx4*>(&s_dco[0][4 * (tid & 3)]);
+    cb = *reinterpret_cast<const floatx4*>(&s_dco[1][4 * (tid & 3)]);
+    cc = *reinterpret_cast<const floatx4*>(&s_dco[2][4 * (tid & 3)]);
+  }
   for (int buf = 0; tile < total_tiles; tile += gridDim.x, buf ^= 1) {
     if (tid < kChunks) stem_stage(plane[buf], pf, tid);
     float* sdst = sdy[buf] + (tid >> 2) * DS + 4 * (tid & 3);   // chunk tid + 256 k: pixel tid / 4 + 64 k
-    *reinterpret_cast<float4*>(sdst) = pd0;
-    *reinterpret_cast<float4*>(sdst + 64 * DS) = pd1;
-    *reinterpret_cast<float4*>(sdst + 128 * DS) = pd2;
-    *reinterpret_cast<float4*>(sdst + 192 * DS) = pd3;
+    if (DYBN) {
+      pd0 = ca * pd0 + (cb * pc0 + cc);
+      pd1 = ca * pd1 + (cb * pc1 + cc);
+      pd2 = ca * pd2 + (cb * pc2 + cc);
+      pd3 = ca * pd3 + (cb * pc3 + cc);
+    }
+    *reinterpret_cast<floatx4*>(sdst) = pd0;
+    *reinterpret_cast<floatx4*>(sdst + 64 * DS) = pd1;
+    *reinterpret_cast<floatx4*>(sdst + 128 * DS) = pd2;
+    *reinterpret_cast<floatx4*>(sdst + 192 * DS) = pd3;
     __syncthreads();
     const int nxt = tile + gridDim.x;
     if (nxt < total_tiles) {
@@ -210,8 +252,14 @@ void conv_stem_fwd(const ConvStemArgs& a, hipStream_t stream) {
 
 void conv_stem_wgrad(const ConvStemArgs& a, hipStream_t stream) {
   if (a.B < 1 || !a.x || !a.dy || !a.dw) throw std::runtime_error("conv_stem_wgrad: null operand or empty batch");
-  static const int bpc = stem_blocks_per_cu(conv_stem_wgrad_kernel);
-  launch("conv_stem_wgrad", conv_stem_wgrad_kernel, dim3(stem_grid(4 * a.B, 256 * (bpc > 2 ? 2 : bpc))), dim3(256), 0, stream, a);
+  if (a.dy_x) {
+    if (!a.dy_bn.sums || !a.dy_bn.gamma || !a.dy_gsums) throw std::runtime_error("conv_stem_wgrad: the BatchNorm prologue needs its statistics");
+    static const int bpc = stem_blocks_per_cu(conv_stem_wgrad_kernel<true>);
+    launch("conv_stem_wgrad", conv_stem_wgrad_kernel<true>, dim3(stem_grid(4 * a.B, 256 * (bpc > 2 ? 2 : bpc))), dim3(256), 0, stream, a);
+    return;
+  }
+  static const int bpc = stem_blocks_per_cu(conv_stem_wgrad_kernel<false>);
+  launch("conv_stem_wgrad", conv_stem_wgrad_kernel<false>, dim3(stem_grid(4 * a.B, 256 * (bpc > 2 ? 2 : bpc))), dim3(256), 0, stream, a);
 }
 
 }  // namespace dtf

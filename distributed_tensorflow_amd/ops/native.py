@@ -306,8 +306,12 @@ def conv_stem_fwd(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] 
     return out
 
 
-def conv_stem_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, slot_stride: int = 0) -> None:
-    """dw [3,3,3,16] += filter gradient of conv_stem_fwd (per-XCD copies with slot_stride)."""
+def conv_stem_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, slot_stride: int = 0,
+                    dy_bn=None, dy_dgamma=None, dy_dbeta=None) -> None:
+    """dw [3,3,3,16] += filter gradient of conv_stem_fwd (per-XCD copies with slot_stride).
+    dy_bn = (y, BnState of y, backward sums): `dy` is the masked gradient at the output of the
+    BatchNorm after the stem and that BatchNorm's backward is applied while dy is staged (as in
+    conv_bwd_fused); dy_dgamma / dy_dbeta receive its parameter gradients."""
     require()
     b = int(x.shape[0])
     if tuple(x.shape[1:]) != (32, 32, 3) or tuple(dy.shape) != (b, 32, 32, 16) or dw.numel() != 27 * 16:
@@ -316,7 +320,18 @@ def conv_stem_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, slot_st
         last = (dw.storage_offset() + (STAT_SLOTS - 1) * slot_stride + dw.numel()) * 4
         if slot_stride < dw.numel() or last > dw.untyped_storage().nbytes():
             raise ValueError("conv_stem_wgrad: the slot copies do not fit dw's storage")
-    hip().conv_stem_wgrad(dict(x=_chk(x, "x"), dy=_chk(dy, "dy"), dw=_chk(dw, "dw"), slot_stride=slot_stride, B=b), stream())
+    d = dict(x=_chk(x, "x"), dy=_chk(dy, "dy"), dw=_chk(dw, "dw"), slot_stride=slot_stride, B=b)
+    if dy_bn is not None:
+        y, ybn, ygs = dy_bn
+        if tuple(y.shape) != (b, 32, 32, 16) or ybn.channels != 16 or ygs.numel() != STAT_SLOTS * 32:
+            raise ValueError("conv_stem_wgrad: dy_bn operands have the wrong shape")
+        d.update(dy_x=_chk(y, "dy_x"), dy_bn=ybn.ref(), dy_gsums=_chk(ygs, "dy_gsums", torch.float64))
+        for key, t in (("dy_dgamma", dy_dgamma), ("dy_dbeta", dy_dbeta)):
+            if t is not None:
+                if t.numel() != 16:
+                    raise ValueError(f"{key} must have 16 elements")
+                d[key] = _chk(t, key)
+    hip().conv_stem_wgrad(d, stream())
 
 
 def conv5x5_tile_supported(h: int, w_: int, cin: int, cout: int) -> bool:

@@ -756,6 +756,34 @@ def test_program_record_run_and_graph_replay():
     assert float(x[n - 1]) == 18.0 * 36.0
 
 
+def test_conv_stem_filter_gradient_with_bn_backward_prologue():
+    # images -> stem conv -> y -> bn/relu -> (rest): the stem's filter gradient takes the masked
+    # gradient at the BatchNorm output and applies the BatchNorm backward while staging it
+    b, c = 37, 16
+    x = rnd(b, 32, 32, 3)
+    w = rnd(3, 3, 3, c, scale=0.3).requires_grad_(True)
+    gam = (rnd(c, seed=71).abs() + 0.5).requires_grad_(True)
+    bet = rnd(c, scale=0.3, seed=72).requires_grad_(True)
+    y = ref.conv2d_same(x, w, 1)
+    u = ref.batch_norm(y, gam, bet)
+    u.retain_grad()
+    r = torch.relu(u)
+    dr = rnd(*r.shape, seed=73)
+    dw_want, dg, db = torch.autograd.grad((r * dr).sum(), (w, gam, bet), retain_graph=True)
+    (du,) = torch.autograd.grad((r * dr).sum(), u)          # masked by relu'
+    yd = y.detach()
+    mean, var = ref.batch_moments(yd)
+    yhat = (yd - mean) * torch.rsqrt(var + ref.BN_EPSILON)
+    gs = nv.stats_from_totals(torch.cat([du.reshape(-1, c).double().sum(0), (du * yhat).reshape(-1, c).double().sum(0)]))
+    slots = torch.zeros(nv.STAT_SLOTS, 512, device=DEV)
+    dgam, dbet = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    nv.conv_stem_wgrad(x, du.contiguous(), slots[0, :432].view(3, 3, 3, c), slot_stride=512,
+                       dy_bn=(yd, bn_state_for(yd, gam.detach(), bet.detach()), gs), dy_dgamma=dgam, dy_dbeta=dbet)
+    close(slots[:, :432].sum(0).view(3, 3, 3, c), dw_want, 2e-4)
+    close(dgam, dg, 1e-4)
+    close(dbet, db, 1e-4)
+
+
 def test_zero_multi_clears_every_buffer_and_nothing_else():
     sizes = [4, 20, 1 << 16, 272476 // 4 * 4, 8]
     guard = 8

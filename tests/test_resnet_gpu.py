@@ -144,7 +144,7 @@ def test_gpu_batcher_matches_host_batcher():
 
 @pytest.mark.parametrize("env", [dict(DTF_BWD_FUSED="0", DTF_SIDE_STREAM="1"), dict(DTF_BWD_FUSED="0", DTF_SIDE_STREAM="0"),
                                  dict(DTF_BWD_FUSED="1", DTF_SIDE_STREAM="1"),
-                                 dict(DTF_BWD_FUSED="1", DTF_SIDE_STREAM="0", DTF_BWD_SHORTCUT_FUSE=""),
+                                 dict(DTF_BWD_FUSED="1", DTF_SIDE_STREAM="0", DTF_BWD_SHORTCUT_FUSE="", DTF_BWD_STEM_FOLD="0"),
                                  dict(DTF_BWD_FUSED="1", DTF_SIDE_STREAM="0", DTF_BWD_SHORTCUT_FUSE="16,32,64")])
 def test_backward_variants_agree(monkeypatch, env):
     """Separate data/filter-gradient kernels (with the filter gradients on a side lane or not), the
