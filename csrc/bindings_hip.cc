@@ -94,7 +94,7 @@ PYBIND11_MODULE(_hip, m) {
     V(dw_slot_stride); a.bn = as_bn(d, "bn"); P(gsums, double); P(extra, const float);
     V(B); V(H); V(W); V(C);
     P(dy_x, const float); a.dy_bn = as_bn(d, "dy_bn"); P(dy_gsums, const double); P(dy_dgamma, float); P(dy_dbeta, float);
-    P(dy_res, const float); P(dy_out, float);
+    P(dy_res, const float); P(dy_out, float); V(dy_res_mode);
     P(tile_counters, int);
     return conv_bwd_fused(a, as_stream(stream));
   });

@@ -135,6 +135,10 @@ struct ConvBwdFusedArgs {
   // block before needs again, is produced here instead of by a separate elementwise pass.
   const float* dy_res;     // [B,H,W,C], nullable
   float* dy_out;           // [B,H,W,C], required with dy_res
+  // dy_res_mode 1: the block after this layer's halves the resolution and doubles the channels
+  // (option-A shortcut: 2x2 average pool, channels zero-padded by C/2 on each side); dy_res is
+  // then its output gradient [B,H/2,W/2,2C] and the term is dy_res[n, y/2, x/2, C/2 + c] / 4.
+  int dy_res_mode;
   // Optional dynamic tile scheduling: kBwdTileCounters zeroed ints. A block takes its first two
   // bands statically and every further one from the counter of its XCD (and channel split), so
   // when some CUs are shared with another kernel (an all-reduce of an earlier gradient bucket, a

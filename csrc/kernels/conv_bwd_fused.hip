@@ -71,7 +71,7 @@ struct BF {
   static_assert(TW % 8 == 0 && (TH * TW) % 16 == 0, "k-steps are taken from 16-pixel segments of whole rows");
 };
 
-template <int C, int NT, int TW, int TH, bool DYBN, bool RES = false>
+template <int C, int NT, int TW, int TH, bool DYBN, int RES = 0>   // RES: 0 none, 1 identity shortcut, 2 option-A shortcut
 __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs a) {
   static_assert(!RES || DYBN, "the shortcut term rides on the BatchNorm prologue");
   using G = BF<C, NT, TW, TH>;
@@ -156,6 +156,16 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
   floatx4 pf_d[G::NPF_D], pf_x[G::NPF_X];
   floatx4 pf_c[DYBN ? G::NPF_D : 1];
   floatx4 pf_r[RES ? G::NPF_D : 1];
+  int r_goff[RES == 2 ? G::NPF_D : 1];   // option-A shortcut: offset of the chunk's source in the half-resolution gradient
+  if (RES == 2) {
+#pragma unroll
+    for (int k = 0; k < G::NPF_D; ++k) {
+      const int i = tid + k * 256;
+      const int pix = i / (C / 4), c4 = i % (C / 4);
+      const int r = pix / LW, ix = pix % LW - 1;
+      r_goff[k] = (((r - 1) >> 1) * (TW / 2) + (ix >> 1)) * (2 * C) + C / 2 + c4 * 4;   // row r of the halo tile is image row oy0 - 1 + r
+    }
+  }
   unsigned okbits = 0;
   auto load_band = [&](int t) {
     const int n = t / bands;
@@ -190,10 +200,11 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
   auto load_res = [&](int t) {
     const int n = t / bands;
     const int oy0 = (t - n * bands) * TH;
-    const float* r0 = a.dy_res + ((long long)(n * a.H + oy0 - 1) * a.W) * C;
+    const float* r0 = RES == 2 ? a.dy_res + ((long long)(n * (a.H / 2) + oy0 / 2) * (TW / 2)) * (2 * C)
+                               : a.dy_res + ((long long)(n * a.H + oy0 - 1) * a.W) * C;
 #pragma unroll
     for (int k = 0; k < G::NPF_D; ++k)
-      if ((okbits >> k) & 1u) pf_r[k] = *reinterpret_cast<const floatx4*>(r0 + d_goff[k]);
+      if ((okbits >> k) & 1u) pf_r[k] = *reinterpret_cast<const floatx4*>(r0 + (RES == 2 ? r_goff[k] : d_goff[k]));
   };
   auto write_band = [&](long long doff) {
 #pragma unroll
@@ -209,7 +220,8 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = ca[e] * v[e] + (cb[e] * pf_c[k][e] + cc[e]);
           if (RES) {
-            v += pf_r[k];
+            if (RES == 2) v += 0.25f * pf_r[k];
+            else v += pf_r[k];
             // the band's own rows (not the halo) of this block's channel slice leave as the block input gradient
             const int row = (d_lr[k] >> 16) - 1;
             if (row >= 1 && row <= TH && (unsigned)(ch - c0) < (unsigned)XC) *reinterpret_cast<floatx4*>(a.dy_out + doff + d_goff[k]) = v;
@@ -431,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
   }
 }
 
-template <int C, int NT, int TW, int TH, bool DYBN, bool RES = false>
+template <int C, int NT, int TW, int TH, bool DYBN, int RES = 0>
 size_t launch_bf(const ConvBwdFusedArgs& a, hipStream_t stream) {
   using G = BF<C, NT, TW, TH>;
   const size_t shmem = (size_t)G::LDS_FLOATS * sizeof(float);
@@ -470,9 +482,14 @@ size_t conv_bwd_fused(const ConvBwdFusedArgs& a, hipStream_t stream) {
     if (!a.dy_bn.sums || !a.dy_gsums) throw std::runtime_error("conv_bwd_fused: the BatchNorm prologue needs its statistics");
     if (a.dy_res) {
       if (!a.dy_out) throw std::runtime_error("conv_bwd_fused: dy_res needs dy_out");
-      if (a.C == 16) return launch_bf<16, 1, 32, 4, true, true>(a, stream);
-      if (a.C == 32) return launch_bf<32, 1, 16, 8, true, true>(a, stream);
-      return launch_bf<64, 1, 8, 8, true, true>(a, stream);
+      if (a.dy_res_mode == 1) {
+        if (a.C == 16) return launch_bf<16, 1, 32, 4, true, 2>(a, stream);
+        if (a.C == 32) return launch_bf<32, 1, 16, 8, true, 2>(a, stream);
+        throw std::runtime_error("conv_bwd_fused: no option-A shortcut behind a 64-channel stage");
+      }
+      if (a.C == 16) return launch_bf<16, 1, 32, 4, true, 1>(a, stream);
+      if (a.C == 32) return launch_bf<32, 1, 16, 8, true, 1>(a, stream);
+      return launch_bf<64, 1, 8, 8, true, 1>(a, stream);
     }
     if (a.C == 16) return launch_bf<16, 1, 32, 8, true>(a, stream);
     if (a.C == 32) return launch_bf<32, 1, 16, 8, true>(a, stream);

@@ -279,7 +279,7 @@ class ResNetHipStep(StepProgramBase):
                     y_t, ybn = dout_bn
                     kw = dict(dy_bn=(y_t, ybn.fwd, ybn.gsums), dy_dgamma=a.grad(ybn.gamma_name), dy_dbeta=a.grad(ybn.beta_name))
                     if shortcut is not None:
-                        kw.update(dy_res=shortcut[0], dy_out=shortcut[1])
+                        kw.update(dy_res=shortcut[0], dy_out=shortcut[1], dy_res_option_a=shortcut[2])
                 if self.dynamic_tiles:
                     nctr = nv.hip().BWD_TILE_COUNTERS
                     kw["tile_counters"] = self._tile_ctr[self._tile_ctr_used:self._tile_ctr_used + nctr]
@@ -305,7 +305,7 @@ class ResNetHipStep(StepProgramBase):
         nv.head_bwd(x_last, self.bnf.fwd, a.param("fc/fc_weights"), self.feat, self.dlogits, dy, self.bnf.gsums,
                     a.grad("fc/fc_weights"), a.grad("fc/fc_bias"))
         nv.bn_bwd_apply(dy, x_last, self.bnf.fwd, self.bnf.gsums, dgamma=a.grad("fc/gamma"), dbeta=a.grad("fc/beta"), out=dy)
-        # An identity block's last step, d(block input) = BN1-backward(g1) + d(block output), is
+        # A block's last step, d(block input) = BN1-backward(g1) + shortcut gradient of d(block output), is
         # folded into the convolution that consumes it (conv2 of the block before) for the channel
         # counts in DTF_BWD_SHORTCUT_FUSE: that kernel stages the sum from its three operands and
         # writes it out for the shortcut of the block before. Measured at batch 1024, per block:
@@ -319,14 +319,16 @@ class ResNetHipStep(StepProgramBase):
             if k == 0 or k in marks or not self.fused_backward:
                 return False
             blk, prev = blocks[k], blocks[k - 1]
-            if blk.first_block or blk.increase_dim or blk.conv1.cin not in fuse_c:
+            if blk.first_block or blk.conv1.cin not in fuse_c:
                 return False
+            if blk.increase_dim:   # option-A shortcut: conv1 is the stride-2 layer, its g1 comes from the separate kernels
+                return fusable(self.c1[k - 1], prev.conv2)
             return fusable(self.y[k - 1], blk.conv1) and fusable(self.c1[k - 1], prev.conv2)
 
         # The first block's g1 feeds nothing but the stem's filter gradient, whose kernel applies
         # BN0's backward in its staging prologue (-35 us of elementwise pass at batch 1024).
         stem_fold = self.fused_backward and os.environ.get("DTF_BWD_STEM_FOLD", "1") != "0"
-        pending = None   # (raw g1 of the block after, its input, its BN1, its output gradient)
+        pending = None   # (raw g1 of the block after, its input, its BN1, its output gradient, option-A shortcut?)
         for k in range(len(blocks) - 1, -1, -1):
             blk = blocks[k]
             x_in = self.c0 if k == 0 else self.y[k - 1]
@@ -336,8 +338,8 @@ class ResNetHipStep(StepProgramBase):
             dy = self._d_out[k]
             # conv2: filter gradient + masked data gradient, then BN backward
             if pending is not None:
-                g_raw, nx_in, nbn1, ndy = pending
-                g2 = layer_backward(c1, g_raw, blk.conv2, bn2, self._d_c1[k], dout_bn=(nx_in, nbn1), shortcut=(ndy, dy))
+                g_raw, nx_in, nbn1, ndy, opt_a = pending
+                g2 = layer_backward(c1, g_raw, blk.conv2, bn2, self._d_c1[k], dout_bn=(nx_in, nbn1), shortcut=(ndy, dy, opt_a))
                 pending = None
             else:
                 g2 = layer_backward(c1, dy, blk.conv2, bn2, self._d_c1[k])
@@ -358,7 +360,7 @@ class ResNetHipStep(StepProgramBase):
                                       out=g2)
                 g1 = layer_backward(x_in, dc1, blk.conv1, bn1, g1_out, extra=dy if blk.first_block else None)
             if fold:
-                pending = (g1, x_in, bn1, dy)
+                pending = (g1, x_in, bn1, dy, blk.increase_dim)
             elif k == 0 and blk.first_block and stem_fold:
                 pass   # BN0's backward is applied by the stem's filter-gradient kernel while it stages g1
             else:

@@ -460,7 +460,8 @@ def conv_bwd_fused_supported(x: torch.Tensor) -> bool:
 
 
 def conv_bwd_fused(dy, x, bn: BnState, wpk_t, dw, gsums, *, slot_stride: int = 0, extra=None, out=None,
-                   dy_bn=None, dy_dgamma=None, dy_dbeta=None, dy_res=None, dy_out=None, tile_counters=None):
+                   dy_bn=None, dy_dgamma=None, dy_dbeta=None, dy_res=None, dy_out=None, dy_res_option_a=False,
+                   tile_counters=None):
     """Backward of y = conv3x3(relu(bn(x)), W), stride 1, in one kernel: returns the masked data
     gradient g, adds (sum g, sum g*xhat) to `gsums` and the filter gradient to `dw`
     (see csrc/kernels/conv.h: ConvBwdFusedArgs).
@@ -469,7 +470,9 @@ def conv_bwd_fused(dy, x, bn: BnState, wpk_t, dw, gsums, *, slot_stride: int = 0
     at the output of the BatchNorm that follows the convolution, and the BatchNorm input gradient
     is formed on the fly; dy_dgamma / dy_dbeta receive that BatchNorm's parameter gradients.
     With dy_res / dy_out (and dy_bn) the gradient of an identity shortcut is added to that
-    BatchNorm input gradient and the sum is written to dy_out (a buffer other than dy)."""
+    BatchNorm input gradient and the sum is written to dy_out (a buffer other than dy); with
+    dy_res_option_a the shortcut is the resolution-halving one (2x2 average pool + channel padding)
+    and dy_res is the [B, H/2, W/2, 2C] gradient at its output."""
     require()
     b, h, w_, c = x.shape
     if tuple(dy.shape) != (b, h, w_, c) or tuple(dw.shape) != (3, 3, c, c) or bn.channels != c:
@@ -505,12 +508,16 @@ def conv_bwd_fused(dy, x, bn: BnState, wpk_t, dw, gsums, *, slot_stride: int = 0
     if (dy_res is None) != (dy_out is None) or (dy_res is not None and dy_bn is None):
         raise ValueError("conv_bwd_fused: dy_res, dy_out and dy_bn go together")
     if dy_res is not None:
-        if tuple(dy_res.shape) != (b, h, w_, c) or tuple(dy_out.shape) != (b, h, w_, c):
+        want_res = (b, h // 2, w_ // 2, 2 * c) if dy_res_option_a else (b, h, w_, c)
+        if tuple(dy_res.shape) != want_res or tuple(dy_out.shape) != (b, h, w_, c):
             raise ValueError("conv_bwd_fused: dy_res / dy_out have the wrong shape")
+        if dy_res_option_a and c == 64:
+            raise ValueError("conv_bwd_fused: no option-A shortcut behind a 64-channel stage")
         if dy_out.data_ptr() in (dy.data_ptr(), dy_res.data_ptr(), x.data_ptr(), out.data_ptr()):
             raise ValueError("conv_bwd_fused: dy_out must not alias an operand (other bands still read their halo rows)")
         d["dy_res"] = _chk(dy_res, "dy_res")
         d["dy_out"] = _chk(dy_out, "dy_out")
+        d["dy_res_mode"] = 1 if dy_res_option_a else 0
     if tile_counters is not None:
         # zeroed int32 block: bands are handed out dynamically (robust when CUs are shared with a collective)
         if tile_counters.dtype != torch.int32 or tile_counters.numel() < hip().BWD_TILE_COUNTERS:

@@ -368,8 +368,9 @@ def test_conv_bwd_fused_with_bn_backward_prologue(shape):
     close(dbet, db2, 1e-4)
 
 
+@pytest.mark.parametrize("option_a", [False, True])
 @pytest.mark.parametrize("shape", [(5, 32, 16), (6, 16, 32), (9, 8, 64), (300, 32, 16), (260, 16, 32)])
-def test_conv_bwd_fused_prologue_with_shortcut_gradient(shape):
+def test_conv_bwd_fused_prologue_with_shortcut_gradient(shape, option_a):
     # as above, and y also feeds an identity shortcut whose gradient `res` arrives from the block
     # after: the kernel stages dy = bn2_backward(du2) + res and writes it out as the block input gradient
     b, h, c = shape
@@ -385,8 +386,17 @@ def test_conv_bwd_fused_prologue_with_shortcut_gradient(shape):
     u2 = ref.batch_norm(y, g2, b2)
     z = ref.conv2d_same(torch.relu(u2), w2, 1)
     dz = rnd(*z.shape, seed=64)
-    res = rnd(*y.shape, seed=65)
-    loss = (z * dz).sum() + (y * res).sum()
+    if option_a:
+        if c == 64:
+            pytest.skip("the 64-channel stage is the last one")
+        # y also feeds the resolution-halving shortcut: 2x2 average pool, C/2 zero channels each side
+        res = rnd(b, h // 2, h // 2, 2 * c, seed=65)
+        pooled = torch.nn.functional.avg_pool2d(y.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+        short = torch.nn.functional.pad(pooled, (c // 2, c // 2))
+        loss = (z * dz).sum() + (short * res).sum()
+    else:
+        res = rnd(*y.shape, seed=65)
+        loss = (z * dz).sum() + (y * res).sum()
     da1, dw1, dg2, db2, dy_total = torch.autograd.grad(loss, (a1, w1, g2, b2, y), retain_graph=True)
     (du2,) = torch.autograd.grad((z * dz).sum(), u2)
     want_g = torch.where(ref.batch_norm(x, g1, b1) > 0, da1, torch.zeros_like(da1))
@@ -402,7 +412,7 @@ def test_conv_bwd_fused_prologue_with_shortcut_gradient(shape):
     got = nv.conv_bwd_fused(du2.contiguous(), x, bn_state_for(x, g1, b1), nv.pack_weights(w1.detach(), flip=True),
                             slots[0].view(3, 3, c, c), gs1, slot_stride=n,
                             dy_bn=(yd, bn_state_for(yd, g2.detach(), b2.detach()), gs2), dy_dgamma=dgam, dy_dbeta=dbet,
-                            dy_res=res, dy_out=dy_out)
+                            dy_res=res, dy_out=dy_out, dy_res_option_a=option_a)
     close(dy_out, dy_total, 2e-4)
     close(got, want_g, 2e-4)
     close(slots.sum(0).view(dw1.shape), dw1, 2e-4)
