@@ -387,7 +387,9 @@ size_t launch_fband(const ConvFpropArgs& a, hipStream_t stream) {
     ensure_dynamic_lds(reinterpret_cast<const void*>(conv_fprop_band_kernel<S, CP, NT, TW, TH, UPS, BWD>), shmem);
     int n = 0;
     DTF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_fprop_band_kernel<S, CP, NT, TW, TH, UPS, BWD>, 256, shmem));
-    return n < 1 ? 1 : n;
+    // the 16- and 64-channel instances would fit three workgroups per CU; a third one measures
+    // slower (ResNet-20 step at batch 1024: 2.83 ms with two everywhere, 2.99 ms with three)
+    return n < 1 ? 1 : (n > 2 ? 2 : n);
   }();
   int gpz_max = (256 * bpc) / zsplit;
   if (gpz_max < 8) gpz_max = 8;
