@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
         floatx4 v = pf_d[k];
         if (DYBN && ((okbits >> k) & 1u)) {
           // BatchNorm backward of the following layer, applied while staging (zero padding stays zero)
-          const int ch = (d_lr[k] & 0xffff) % CPP;
+          static_assert(256 % (C / 4) == 0, "a thread's chunks share their channel group");
+          const int ch = (tid % (C / 4)) * 4;   // the same four channels for every chunk of the thread
           const floatx4 ca = *reinterpret_cast<const floatx4*>(s_dco + ch);
           const floatx4 cb = *reinterpret_cast<const floatx4*>(s_dco + C + ch);
           const floatx4 cc = *reinterpret_cast<const floatx4*>(s_dco + 2 * C + ch);

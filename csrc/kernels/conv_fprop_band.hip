@@ -184,7 +184,9 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_band_kernel(ConvFpropArgs a
       if (tid + k * 256 < G::IN_CHUNKS) {
         floatx4 v = pf[k];
         if (!BWD && a.in_mode == IN_BNRELU && ((okbits >> k) & 1u)) {
-          const int ch = in_loff[k] % CPP;
+          // chunk tid + 256 k carries channels 4 ((tid + 256 k) % C4) ..: the same four for every k
+          static_assert(256 % C4 == 0, "a thread's chunks share their channel group");
+          const int ch = (tid % C4) * 4;
           const floatx4 sc = *reinterpret_cast<const floatx4*>(s_bn + ch);
           const floatx4 sh = *reinterpret_cast<const floatx4*>(s_bn + CP + ch);
 #pragma unroll

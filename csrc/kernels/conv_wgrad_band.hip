@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(ConvWgradArgs a
       if (tid + k * 256 < G::IN_CHUNKS) {
         floatx4 v = pf_in[k];
         if (a.in_mode == IN_BNRELU && ((okbits >> k) & 1u)) {
-          const int ch = in_loff[k] % CPP;   // = c4*4
+          const int ch = (tid % C4) * 4;   // chunk tid + 256 k: the same four channels for every k (256 % C4 == 0)
           const floatx4 sc = *reinterpret_cast<const floatx4*>(s_bn + ch);
           const floatx4 sh = *reinterpret_cast<const floatx4*>(s_bn + CP + ch);
 #pragma unroll
