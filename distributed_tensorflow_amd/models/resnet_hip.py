@@ -1,16 +1,18 @@
 """Fused MI355X training/eval step of the CIFAR ResNet, recorded as a step program.
 
-The whole step is a flat list of ~(6n+1)*4 kernel launches over pre-allocated buffers:
+The whole step is a flat list of kernel launches over pre-allocated buffers (51 for ResNet-20):
 
   forward   one implicit-GEMM conv kernel per layer; the producer's BatchNorm+ReLU is applied
             while the input tile is staged into LDS, the residual add (identity / option-A /
             BN+ReLU'd stem) and the NEXT BatchNorm's batch statistics are fused into the
             epilogue. No normalised activation is ever written to HBM.
   head      BN+ReLU+global-average-pool+FC+softmax-cross-entropy in one kernel.
-  backward  per conv: filter gradient (input re-activated on the fly), data gradient whose
-            epilogue applies the ReLU mask and accumulates BatchNorm-backward's two reductions,
-            then one elementwise kernel that finishes BatchNorm-backward and adds the shortcut
-            gradient.
+  backward  one kernel per stride-1 conv: masked data gradient + BatchNorm-backward's two
+            reductions + filter gradient; the BatchNorm backward of the layer after it and the
+            shortcut gradient are applied while that kernel stages its output gradient (the block
+            input gradient is written once, by the convolution that consumes it). Stride-2 convs
+            use separate data- / filter-gradient kernels and an elementwise BatchNorm-backward
+            pass; the stem's filter-gradient kernel applies BN0's backward in its prologue.
   update    one fused Adam (or momentum-SGD + weight decay) launch over the flat arena.
 
 The program is recorded once (no launches), then replayed either from C++ or as a hipGraph.
