@@ -317,11 +317,15 @@ __global__ __launch_bounds__(256) void zero_multi_kernel(ZeroMultiArgs a) {
 }
 
 __global__ __launch_bounds__(256) void pack_multi_kernel(PackMultiArgs a) {
-  // Find this block's table entry (entries are sorted by first_block).
-  int e = 0;
-  for (int k = 1; k < a.n_entries; ++k)
-    if ((int)blockIdx.x >= a.table[k].first_block) e = k;
-  const PackEntry t = a.table[e];
+  // Find this block's table entry (entries are sorted by first_block): every lane tests one entry,
+  // so the search costs one memory round trip instead of one per entry.
+  int below = 0;
+  for (int k0 = 0; k0 < a.n_entries; k0 += 64) {
+    const int k = k0 + (int)(threadIdx.x & 63);
+    const bool hit = k < a.n_entries && (int)blockIdx.x >= a.table[k].first_block;
+    below += __popcll(__ballot(hit));
+  }
+  const PackEntry t = a.table[below > 0 ? below - 1 : 0];
   const int ks = t.ks;
   const int cin_e = t.transpose_flip ? t.Cout : t.Cin;
   const int cout_e = t.transpose_flip ? t.Cin : t.Cout;
