@@ -55,7 +55,7 @@ def bench_policy(args) -> None:
     world = comm.world
     torch.manual_seed(1234 + comm.rank)
     replica = HipReplica("resnet", args.batch, num_residual_blocks=MODELS[args.model], optimizer=args.optimizer,
-                         num_buckets=args.buckets if world > 1 else 1, weight_decay=2e-4)
+                         num_buckets=(args.buckets or 3) if world > 1 else 1, weight_decay=2e-4)
     with replica.stream_ctx():
         comm.broadcast(replica.arena.params, 0)
     board = None
@@ -137,7 +137,8 @@ def main() -> None:
                          "take ~1.5 GB of the 288 GB HBM and each layer launches >=2 workgroups per CU); the reference's "
                          "launcher uses 256 per worker (DistributedResNet/tools/tf_ec2.py:88), reproduce with --batch 256")
     ap.add_argument("--optimizer", default="adam", choices=["adam", "momentum"])
-    ap.add_argument("--buckets", type=int, default=3, help="gradient buckets overlapped with backward (N>1)")
+    ap.add_argument("--buckets", type=int, default=0,
+                    help="gradient buckets overlapped with backward (N>1); 0 = by gradient size (parallel/comm.py: default_grad_buckets)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the recorded step as a hipGraph (on) or issue it from C++ on two streams (off); auto picks "
                          "the two-stream issue when the step uses a side stream: hipGraph replay serialises on ~10 us "
@@ -175,6 +176,11 @@ def main() -> None:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     n = MODELS[args.model]
     torch.manual_seed(1234 + comm.rank)
+    if args.buckets <= 0:
+        from distributed_tensorflow_amd.models.resnet import resnet_param_specs
+        from distributed_tensorflow_amd.parallel.comm import default_grad_buckets
+
+        args.buckets = default_grad_buckets(sum(sp.numel for sp in resnet_param_specs(n)))
 
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
@@ -206,7 +212,10 @@ def main() -> None:
             for i in range(nseg - 1):
                 step.run(i, graph)
                 lo, hi = ranges[i]
-                comm.all_reduce_async(grads[lo:hi])
+                if i < nseg - 2:
+                    comm.all_reduce_async(grads[lo:hi])   # overlaps the rest of backward
+                else:
+                    comm.all_reduce_inline(grads[lo:hi])  # nothing left to overlap with: no stream hand-offs
             comm.wait_all()
             step.run(nseg - 1, graph)
 

@@ -232,7 +232,8 @@ def define_extension_flags() -> None:
     DEFINE_boolean("async_method", False, "Asynchronous SGD over staleness-bounded parameter shards")
     DEFINE_integer("staleness_bound", 4, "Async mode: gradients older than this many updates are dropped")
     DEFINE_boolean("weighted_grads_method", False, "Least-squares weighted gradient aggregation with simulated worker kills")
-    DEFINE_integer("grad_buckets", 3, "Gradient all-reduce buckets overlapped with the backward pass")
+    DEFINE_integer("grad_buckets", 0, "Gradient all-reduce buckets overlapped with the backward pass (0: three for the "
+                   "straggler policies, which poll at bucket boundaries, else by gradient size)")
     DEFINE_boolean("reduce_scatter", False, "Shard the optimizer: reduce-scatter gradients, all-gather parameters")
     DEFINE_boolean("gpu_data_pipeline", True, "On a GPU keep the training set in HBM (ResNet: crop + whiten on the device; LeNet: batches sliced device-to-device)")
     DEFINE_string("allreduce_impl", "rccl", "Gradient all-reduce: rccl (RCCL collectives) or p2p (hand-written two-shot kernel over peer-mapped HBM)")

@@ -21,6 +21,17 @@ import torch
 import torch.distributed as dist
 
 
+def default_grad_buckets(num_params: int) -> int:
+    """Buckets for a gradient of `num_params` fp32 values when nothing else asks for segments.
+    Over xGMI an all-reduce of a few MB is latency bound (tens of microseconds), less than what
+    splitting it costs: every extra bucket is a segment boundary of the step program (~14 us) plus
+    the hand-offs to and from the collective stream. Measured through a one-rank RCCL group,
+    ResNet-20 (1.1 MB) at batch 1024: 2.85 ms per step with one bucket issued on the compute
+    stream, 2.91 ms with three overlapped ones, 2.83 ms without collectives. Larger gradients get
+    three buckets, overlapped with the rest of backward."""
+    return 1 if num_params * 4 <= (4 << 20) else 3
+
+
 @dataclass
 class CommInfo:
     rank: int
@@ -111,6 +122,17 @@ class Communicator:
             flat.copy_(host)
             return
         self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+
+    def all_reduce_inline(self, flat: torch.Tensor) -> None:
+        """SUM all-reduce of a bucket that nothing can overlap with (the last one of a step): a
+        blocking-style call, which the RCCL process group issues on the current stream, so the
+        step pays no event hand-off to and from the group's own stream."""
+        if not self._collectives:
+            return
+        if self.p2p is not None or not flat.is_cuda or self.info.backend != "nccl":
+            self.all_reduce_async(flat)
+            return
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
 
     def wait_all(self) -> None:
         """Orders the current stream (or blocks the host, on gloo) after all pending buckets."""

@@ -63,8 +63,21 @@ class Strategy:
     def _allreduce_full(self, replica, with_aux: bool = False) -> None:
         a = replica.arena
         with replica.stream_ctx():   # collectives order against the replica's compute stream
-            self.comm.all_reduce_async(a.grads_full if with_aux else a.grads)
+            self.comm.all_reduce_inline(a.grads_full if with_aux else a.grads)
             self.comm.wait_all()
+
+    def _bucket_reduce(self, replica):
+        """Callback for forward_backward(on_bucket=...): buckets become final from the end of the
+        arena towards offset 0; all but the last overlap the rest of backward on the collective
+        stream, the last one (nothing left to overlap with) is issued on the compute stream."""
+        grads = replica.arena.grads
+
+        def on_bucket(lo: int, hi: int) -> None:
+            if lo == 0:
+                self.comm.all_reduce_inline(grads[lo:hi])
+            else:
+                self.comm.all_reduce_async(grads[lo:hi])
+        return on_bucket
 
 
 class FullSync(Strategy):
@@ -78,7 +91,7 @@ class FullSync(Strategy):
         t0 = time.time()
         if self.reduce_scatter and self.world > 1:
             return self._step_sharded(replica, lr, t0)
-        replica.forward_backward(on_bucket=lambda lo, hi: self.comm.all_reduce_async(replica.arena.grads[lo:hi]))
+        replica.forward_backward(on_bucket=self._bucket_reduce(replica))
         dt = time.time() - t0
         with replica.stream_ctx():
             self.comm.wait_all()
@@ -119,7 +132,7 @@ class Backup(Strategy):
         t0 = time.time()
         if self.world == 1 or m >= self.world:
             # nothing can be dropped: plain synchronous step
-            replica.forward_backward(on_bucket=lambda lo, hi: self.comm.all_reduce_async(replica.arena.grads[lo:hi]))
+            replica.forward_backward(on_bucket=self._bucket_reduce(replica))
             dt = time.time() - t0
             with replica.stream_ctx():
                 self.comm.wait_all()

@@ -160,7 +160,19 @@ def train(flags, model: str) -> Dict:
 
     # ---- replica + strategy
     strategy_needs_segments = flags.interval_method or flags.soft_kill_method or flags.backup_worker_method
-    buckets = max(1, flags.grad_buckets) if (world > 1 or strategy_needs_segments) else 1
+    if flags.grad_buckets > 0:
+        buckets = flags.grad_buckets
+    elif strategy_needs_segments:
+        buckets = 3
+    else:
+        from ..models.lenet import lenet_param_specs
+        from ..models.resnet import resnet_param_specs
+        from ..parallel.comm import default_grad_buckets
+
+        specs = lenet_param_specs() if model == "lenet" else resnet_param_specs(flags.num_residual_blocks)
+        buckets = default_grad_buckets(sum(sp.numel for sp in specs))
+    if not (world > 1 or strategy_needs_segments):
+        buckets = 1
     replica = make_replica(
         model, batch_size, device, num_residual_blocks=flags.num_residual_blocks, optimizer=flags.optimizer,
         momentum=flags.momentum, weight_decay=flags.weight_decay if flags.optimizer == "momentum" else 0.0,
