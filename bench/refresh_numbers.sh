@@ -12,7 +12,7 @@ for m in sharded backup async; do
   MASTER_PORT=29611 timeout -k 10 200 python bench.py --steps 30 --warmup 5 --mode $m > $O/mode_$m.json 2>$O/mode_$m.err
 done
 timeout -k 10 200 python bench.py --steps 50 --warmup 10 --rehearse-collectives > $O/rehearse.json 2>$O/rehearse.err
-timeout -k 10 200 python bench.py --steps 50 --warmup 10 --rehearse-collectives --buckets 1 > $O/rehearse_1bucket.json 2>$O/rehearse_1bucket.err
+timeout -k 10 200 python bench.py --steps 50 --warmup 10 --rehearse-collectives --buckets 3 > $O/rehearse_3buckets.json 2>$O/rehearse_3buckets.err
 bash bench/driver_throughput.sh resnet > $O/driver_resnet.txt 2>&1
 bash bench/driver_throughput.sh lenet > $O/driver_lenet.txt 2>&1
 timeout -k 10 200 python bench/lenet_bench.py > $O/lenet_bench.txt 2>&1
