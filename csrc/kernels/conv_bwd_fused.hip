@@ -21,10 +21,12 @@
 // split over blocks (zsplit): a block then owns rows [ci slice] of dW and the same channels of g.
 // With the optional prologue (ConvBwdFusedArgs::dy_x) the BatchNorm backward of the FOLLOWING
 // layer is applied to dy while it is staged, so that tensor is never materialised either; with
-// dy_res / dy_out the gradient of an identity shortcut is added and the sum written out once. The
-// third prefetched tensor fits the register file of the 32-channel instance (253 VGPRs); the
-// 16-channel instance runs over 4-row bands for it (212 VGPRs; with 8 rows it spills 34 registers
-// and is slower than the elementwise pass it replaces); the 64-channel instance spills 16. Filter gradients are flushed once per block through LDS into the gradient
+// dy_res / dy_out the gradient of an identity (or option-A) shortcut is added and the sum written
+// out once. The third prefetched tensor fits the register file of the 32- and 64-channel instances
+// (232 / 222 VGPRs); the 16-channel instance runs over 4-row bands for it (189 VGPRs; with 8 rows
+// it spills and is slower than the elementwise pass it replaces). Only the image columns of the
+// dy halo tile are staged (exactly 5 chunks per thread for an 8-row band at every channel count);
+// its two padding columns are zeroed once. Filter gradients are flushed once per block through LDS into the gradient
 // copy of the block's XCD; statistics go to per-XCD slots.
 // (reference ops: conv2d_backprop_input + conv2d_backprop_filter + the BatchNorm / ReLU gradients
 //  under opt.compute_gradients, DistributedResNet/src/distributed_train.py:256)
@@ -43,7 +45,7 @@ struct BF {
   static constexpr int CG = C / 16;
   static constexpr int KG = 9 * CG;
   static constexpr int LH = TH + 2, LW = TW + 2;
-  static constexpr int D_CHUNKS = LH * LW * (C / 4);
+  static constexpr int D_CHUNKS = LH * TW * (C / 4);   // the halo columns are outside the image for every band: zeroed once, never staged
   static constexpr int X_CHUNKS = TH * TW * (XC / 4);
   static constexpr int NPF_D = (D_CHUNKS + 255) / 256;
   static constexpr int NPF_X = (X_CHUNKS + 255) / 256;
@@ -136,10 +138,10 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
 #pragma unroll
   for (int k = 0; k < G::NPF_D; ++k) {
     const int i = tid + k * 256;
-    const int pix = i / (C / 4), c4 = i % (C / 4);
-    const int r = pix / LW, c = pix % LW;
-    const int ix = c - 1;
-    const bool ok = (i < G::D_CHUNKS) && ix >= 0 && ix < a.W;
+    const int ipx = i / (C / 4), c4 = i % (C / 4);
+    const int r = ipx / TW, ix = ipx % TW;      // halo-tile row, image column (a.W == TW)
+    const int pix = r * LW + ix + 1;
+    const bool ok = i < G::D_CHUNKS;
     d_goff[k] = (r * a.W + ix) * C + c4 * 4;
     d_lr[k] = (pix * CPP + c4 * 4) | ((ok ? r + 1 : 0) << 16);
   }
@@ -161,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
 #pragma unroll
     for (int k = 0; k < G::NPF_D; ++k) {
       const int i = tid + k * 256;
-      const int pix = i / (C / 4), c4 = i % (C / 4);
-      const int r = pix / LW, ix = pix % LW - 1;
+      const int ipx = i / (C / 4), c4 = i % (C / 4);
+      const int r = ipx / TW, ix = ipx % TW;
       r_goff[k] = (((r - 1) >> 1) * (TW / 2) + (ix >> 1)) * (2 * C) + C / 2 + c4 * 4;   // row r of the halo tile is image row oy0 - 1 + r
     }
   }
@@ -285,6 +287,11 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
 #pragma unroll
   for (int k = 0; k < G::NW; ++k)
     if (tid + k * 256 < G::W_CHUNKS) reinterpret_cast<floatx4*>(s_w)[tid + k * 256] = wreg[k];
+  // left / right halo column of the dy tile: zero padding for every band
+  for (int i = tid; i < G::LH * 2 * CPP; i += 256) {
+    const int r = i / (2 * CPP), side = (i / CPP) & 1, ch = i % CPP;
+    s_dy[(r * LW + (side ? LW - 1 : 0)) * CPP + ch] = 0.f;
+  }
   __syncthreads();
 
   // ---- per-lane constants -----------------------------------------------------------------------

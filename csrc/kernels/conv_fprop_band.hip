@@ -31,7 +31,10 @@ struct FBand {
   static constexpr int C4 = CP / 4;
   static constexpr int LH = (TH - 1) * S + 3;
   static constexpr int LW = (TW - 1) * S + 3;
-  static constexpr int IN_CHUNKS = LH * LW * C4;
+  // stride 1: the halo tile's first and last column lie outside the image for every band; they are
+  // zeroed once and only the TW image columns are staged (8-row bands: exactly 5 chunks per thread)
+  static constexpr bool INTERIOR = (S == 1) && !UPS;
+  static constexpr int IN_CHUNKS = LH * (INTERIOR ? TW : LW) * C4;
   static constexpr int NPF = (IN_CHUNKS + 255) / 256;
   static constexpr int W_CHUNKS = KG * NT * 64;            // float4s of the filter slice
   static constexpr int NW = (W_CHUNKS + 255) / 256;
@@ -114,8 +117,10 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_band_kernel(ConvFpropArgs a
 #pragma unroll
   for (int k = 0; k < G::NPF; ++k) {
     const int i = tid + k * 256;
-    const int pix = i / C4, c4 = i % C4;
-    const int r = pix / LW, c = pix % LW;
+    const int c4 = i % C4;
+    const int r = G::INTERIOR ? (i / C4) / TW : (i / C4) / LW;
+    const int c = G::INTERIOR ? (i / C4) % TW + 1 : (i / C4) % LW;   // pad = 1 for the stride-1 shapes
+    const int pix = r * LW + c;
     int rr = r, ix = c - a.pad;
     bool ok = i < G::IN_CHUNKS;
     if (UPS) {
@@ -234,6 +239,12 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_band_kernel(ConvFpropArgs a
 #pragma unroll
   for (int k = 0; k < G::NW; ++k)
     if (tid + k * 256 < G::W_CHUNKS) reinterpret_cast<floatx4*>(s_w)[tid + k * 256] = wreg[k];
+  if (G::INTERIOR) {
+    for (int i = tid; i < G::LH * 2 * CPP; i += 256) {
+      const int r = i / (2 * CPP), side = (i / CPP) & 1, ch = i % CPP;
+      s_in[(r * LW + (side ? LW - 1 : 0)) * CPP + ch] = 0.f;
+    }
+  }
   __syncthreads();
 
   float e_scale[NT][4], e_shift[NT][4], e_mean[NT][4], e_rstd[NT][4], e_bias[NT][4];

@@ -311,11 +311,10 @@ class ResNetHipStep(StepProgramBase):
         # folded into the convolution that consumes it (conv2 of the block before) for the channel
         # counts in DTF_BWD_SHORTCUT_FUSE: that kernel stages the sum from its three operands and
         # writes it out for the shortcut of the block before. Measured at batch 1024, per block:
-        # 32 channels 110 -> 102 us, 16 channels 135 -> 112 us (with 4-row bands, the 8-row instance
-        # spills); the 64-channel instance spills and the pass it replaces takes only 13 us, hence the
-        # default. Not across a bucket boundary: BN1's dgamma / dbeta would be written after their
-        # bucket has left.
-        fuse_c = {int(v) for v in os.environ.get("DTF_BWD_SHORTCUT_FUSE", "16,32").split(",") if v.strip()}
+        # 32 channels 110 -> 102 us, 16 channels 135 -> 112 us (over 4-row bands; the 8-row instance
+        # spills), 64 channels 106 -> 103 us. Not across a bucket boundary: BN1's dgamma / dbeta
+        # would be written after their bucket has left.
+        fuse_c = {int(v) for v in os.environ.get("DTF_BWD_SHORTCUT_FUSE", "16,32,64").split(",") if v.strip()}
 
         def folds_into_previous(k):
             if k == 0 or k in marks or not self.fused_backward:

@@ -149,7 +149,7 @@ def test_gpu_batcher_matches_host_batcher():
 def test_backward_variants_agree(monkeypatch, env):
     """Separate data/filter-gradient kernels (with the filter gradients on a side lane or not), the
     fused backward kernels, and the fused kernels with the identity blocks' input gradient folded
-    into the consuming convolution (for no / all channel counts; the default is 16 and 32) must
+    into the consuming convolution (switched off / on) must
     produce the same gradients and the same update."""
     from distributed_tensorflow_amd.models.resnet_hip import ResNetHipStep
 
