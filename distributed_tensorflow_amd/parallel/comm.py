@@ -7,8 +7,9 @@ servers (reference: DistributedLeNet/src/mnist_distributed_train.py:25-35): inst
 per variable per direction per step, a step moves each gradient bucket exactly once.
 
 xGMI is a point-to-point mesh (7 links per GPU), and the gradients here are small (1-7 MB), so
-the exchange is latency bound: the default is one to four large buckets, issued as soon as the
-backward pass has finished the bucket's layers, overlapped with the rest of backward.
+the exchange is latency bound: one bucket (issued on the compute stream behind backward) for
+gradients up to 4 MB, else three large buckets, each issued as soon as the backward pass has
+finished its layers and overlapped with the rest of backward (default_grad_buckets below).
 """
 from __future__ import annotations
 
