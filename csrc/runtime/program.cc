@@ -135,13 +135,14 @@ void Program::instantiate(hipStream_t stream, int seg) {
     (void)hipGraphDestroy(g.graph);
     g.graph = nullptr;
   }
-  // A capture must not run on the legacy default stream.
-  hipStream_t cap = stream;
-  bool own = false;
-  if (cap == nullptr) {
-    DTF_HIP_CHECK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
-    own = true;
-  }
+  // The capture always runs on a stream of its own, never on the caller's: other threads may be
+  // polling events recorded on the caller's stream (the RCCL process group's watchdog does, for
+  // every collective issued there), and querying an event whose stream is capturing is an error
+  // that ends the process. A captured graph is not tied to the stream it was captured on.
+  (void)stream;
+  hipStream_t cap = nullptr;
+  const bool own = true;
+  DTF_HIP_CHECK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
   DTF_HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
   try {
     run(cap, seg);

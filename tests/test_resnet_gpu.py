@@ -204,3 +204,37 @@ def test_bench_contract_one_json_line_through_the_rccl_path():
         d = json.loads(lines[0])
         assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["dtype"] == "fp32"
         assert d["config"]["final_loss"] == d["config"]["final_loss"]   # not NaN
+
+
+def test_graph_capture_next_to_pending_collectives():
+    """The process group's watchdog thread polls the end events of collectives issued on the
+    compute stream; on this ROCm an event query fails, and ends the process, while the event's
+    stream is capturing (bench/micro/event_query_during_capture.py). Step programs are therefore
+    captured on a stream of their own: capture right behind a collective, many times, with a
+    one-rank RCCL group."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import torch, torch.distributed as dist
+from distributed_tensorflow_amd.models.resnet_hip import ResNetHipStep
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    step = ResNetHipStep(1, 8, num_buckets=3)
+    t = torch.ones(1 << 16, device="cuda")
+    for i in range(150):
+        dist.all_reduce(t)                       # end event recorded on the current stream
+        step.instantiate(per_segment=True)       # capture right behind it
+        for seg in range(step.num_segments):
+            step.run(seg, True)
+    s.synchronize()
+dist.destroy_process_group()
+print("ok")
+"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29717", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]
