@@ -107,3 +107,16 @@ def test_own_cfg_files_parse_and_expand():
         assert flags["train_dir"].endswith("/train_dir"), f
         assert int(flags["batch_size"]) > 0
         assert c["base_out_dir"] == "runs/" + c["name"]
+
+
+def test_default_grad_buckets_follow_the_gradient_size():
+    from distributed_tensorflow_amd.models.lenet import lenet_param_specs
+    from distributed_tensorflow_amd.models.resnet import resnet_param_specs
+    from distributed_tensorflow_amd.parallel.comm import default_grad_buckets
+
+    size = lambda specs: sum(sp.numel for sp in specs)
+    assert default_grad_buckets(size(resnet_param_specs(3))) == 1      # ResNet-20: 1.1 MB, latency bound
+    assert default_grad_buckets(size(resnet_param_specs(5))) == 1      # ResNet-32: 1.9 MB
+    assert default_grad_buckets(size(resnet_param_specs(18))) == 3     # ResNet-110: 6.9 MB
+    assert default_grad_buckets(size(lenet_param_specs())) == 3        # LeNet: 13 MB (its program has two segments at most)
+    assert default_grad_buckets((4 << 20) // 4) == 1 and default_grad_buckets((4 << 20) // 4 + 1) == 3
