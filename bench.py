@@ -3,8 +3,12 @@
 
   python bench.py --gpus N --steps K --warmup W [--model resnet20] [--batch 256]
 
-N > 1 is launched by torchrun (one rank per GPU over RCCL); RANK / LOCAL_RANK / WORLD_SIZE /
-MASTER_* come from the environment. Every rank trains the same pre-activation ResNet-(6n+2) on
+N > 1 runs one rank per GPU over RCCL. Under torchrun RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+come from the environment; started plainly as `python bench.py --gpus N` the script starts the N
+ranks itself (fresh child processes, created before anything touches the GPU) and relays rank 0's
+JSON line. It refuses to run when the number of ranks differs from --gpus, or when fewer GPUs than
+ranks are visible (unless --share-gpu asks for a rehearsal of several ranks on one GPU over gloo, in
+which case `n_gpus` reports the distinct GPUs, not the ranks). Every rank trains the same pre-activation ResNet-(6n+2) on
 synthetic CIFAR-shaped data with random-init weights: full forward, backward, gradient
 all-reduce (bucketed, overlapped with backward) and the fused Adam update, all inside the timed
 region, in fp32 (the reference's dtype) on the exact-fp32 matrix cores. Scaling is weak: the
@@ -27,6 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+from distributed_tensorflow_amd import launch  # noqa: E402
+
 MODELS = {"resnet8": 1, "resnet20": 3, "resnet32": 5, "resnet56": 9, "resnet110": 18}
 
 
@@ -41,6 +47,20 @@ def cpu_floor(model: str):
     return None
 
 
+def check_topology(args, comm) -> dict:
+    """Refuses to measure something other than what --gpus asked for; returns the fields that say
+    what the ranks really ran on (backend, ranks, distinct GPUs, ranks that talk through RCCL)."""
+    if comm.world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {comm.world} rank(s); start it with "
+                         f"`python bench.py --gpus {args.gpus}` (it launches the ranks itself) or under torchrun with "
+                         f"--nproc-per-node {args.gpus}")
+    topo = comm.topology()
+    if topo["distinct_gpus"] < comm.world and not args.share_gpu:
+        raise SystemExit(f"bench.py: {comm.world} ranks but only {topo['distinct_gpus']} distinct GPU(s); "
+                         "pass --share-gpu (with --backend gloo) to rehearse several ranks on one GPU")
+    return topo
+
+
 def bench_policy(args) -> None:
     """Images/sec of the non-headline aggregation policies (same model, data, dtype and optimizer
     as the headline; each step is forward + backward + the policy's aggregation + update)."""
@@ -53,6 +73,7 @@ def bench_policy(args) -> None:
         raise SystemExit("bench.py needs an MI355X")
     comm = Communicator.from_env(backend=args.backend, force_group=args.rehearse_collectives)
     world = comm.world
+    topo = check_topology(args, comm)
     torch.manual_seed(1234 + comm.rank)
     replica = HipReplica("resnet", args.batch, num_residual_blocks=MODELS[args.model], optimizer=args.optimizer,
                          num_buckets=(args.buckets or 3) if world > 1 else 1, weight_decay=2e-4)
@@ -110,7 +131,9 @@ def bench_policy(args) -> None:
         floor = cpu_floor(args.model)
         print(json.dumps({
             "metric": "images/sec (node) ResNet CIFAR-10 %s-SGD" % args.mode,
-            "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 1), "unit": "images/sec", "n_gpus": topo["distinct_gpus"], "ranks": world,
+            "backend": topo["backend"], "distinct_gpus": topo["distinct_gpus"], "rccl_ranks": topo["rccl_ranks"],
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": round(value / floor, 2) if floor else None, "dtype": "fp32",
             "data": "synthetic CIFAR-10-shaped images, random-init weights",
@@ -156,10 +179,27 @@ def main() -> None:
                          "--aggregate gradients (masked all-reduce); async = staleness-bounded parameter shards")
     ap.add_argument("--aggregate", type=int, default=0, help="backup mode: gradients per update (default N-1)")
     ap.add_argument("--staleness", type=int, default=4, help="async mode: staleness bound")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="allow more ranks than distinct GPUs (rehearsal of the multi-rank path on one GPU; needs --backend gloo, "
+                         "RCCL refuses two ranks on one device). The JSON then reports n_gpus = distinct GPUs")
     ap.add_argument("--rehearse-collectives", action="store_true",
                     help="one rank only: create the process group anyway and run the bucketed step with its all-reduces "
                          "through the backend (exercises the multi-GPU code path of the step on a single GPU)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and not launch.launched_by_torchrun():
+        # The parent never touches the GPU: it only counts devices (which initialises nothing),
+        # starts one fresh process per rank and relays rank 0's JSON line.
+        ndev = launch.visible_gpus()
+        if ndev < args.gpus and not args.share_gpu:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but {ndev} GPU(s) visible; pass --share-gpu --backend gloo to "
+                             "rehearse several ranks on one GPU")
+        if args.share_gpu and ndev < args.gpus and (args.backend or "nccl") == "nccl":
+            raise SystemExit("bench.py: --share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
+        sys.stdout.flush()
+        code = launch.spawn_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, devices=ndev)
+        raise SystemExit(code)
     if args.mode != "sync":
         return bench_policy(args)
 
@@ -172,8 +212,7 @@ def main() -> None:
     comm = Communicator.from_env(backend=args.backend, force_group=args.rehearse_collectives)
     world = comm.world
     multi = world > 1 or args.rehearse_collectives
-    if world != args.gpus and comm.is_chief:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    topo = check_topology(args, comm)
     n = MODELS[args.model]
     torch.manual_seed(1234 + comm.rank)
     if args.buckets <= 0:
@@ -254,7 +293,11 @@ def main() -> None:
             "metric": "images/sec (node) ResNet CIFAR-10 sync-SGD",
             "value": round(value, 1),
             "unit": "images/sec",
-            "n_gpus": world,
+            "n_gpus": topo["distinct_gpus"],
+            "ranks": world,
+            "backend": topo["backend"],
+            "distinct_gpus": topo["distinct_gpus"],
+            "rccl_ranks": topo["rccl_ranks"],
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms, 4),
@@ -267,7 +310,8 @@ def main() -> None:
             "config": {
                 "model": args.model, "global_batch": args.batch * world, "per_gpu_batch": args.batch,
                 "reference_worker_batch": 256, "seq_len": None, "image": "32x32x3", "optimizer": args.optimizer,
-                "parallelism": f"dp{world}", "hip_graph": graph, "allreduce": args.allreduce if multi else "none", "grad_buckets": len(ranges),
+                "parallelism": f"dp{world}", "hip_graph": graph,
+                "allreduce": ("p2p" if comm.p2p is not None else topo["backend"]) if multi else "none", "grad_buckets": len(ranges),
                 "kernels_per_step": step.kernel_count, "final_loss": round(loss, 4),
                 "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
                 "baseline": "CPU reference floor (bench/cpu_floor.json); the reference publishes no numbers",

@@ -33,6 +33,21 @@ def default_grad_buckets(num_params: int) -> int:
     return 1 if num_params * 4 <= (4 << 20) else 3
 
 
+def device_identity(device: torch.device) -> str:
+    """A string that is equal for two ranks exactly when they sit on the same physical GPU
+    (host name + PCI address, or the device UUID where the driver reports one)."""
+    import socket
+
+    if device.type != "cuda":
+        return "%s/cpu" % socket.gethostname()
+    p = torch.cuda.get_device_properties(device)
+    ident = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+    uuid = getattr(p, "uuid", None)
+    if uuid is not None and str(uuid).strip("0-") != "":
+        ident += "/" + str(uuid)
+    return "%s/%s" % (socket.gethostname(), ident)
+
+
 @dataclass
 class CommInfo:
     rank: int
@@ -205,6 +220,19 @@ class Communicator:
         out = [None] * self.world
         dist.all_gather_object(out, obj)
         return out
+
+    def topology(self) -> dict:
+        """What the ranks of this group really run on: backend, number of ranks, number of
+        DISTINCT physical GPUs (ranks rehearsing on a shared GPU count once), and how many ranks
+        exchange data through RCCL."""
+        ids = self.all_gather_object(device_identity(self.info.device))
+        on_gpu = self.info.device.type == "cuda"
+        return {
+            "backend": self.info.backend if self._collectives else "none",
+            "ranks": self.world,
+            "distinct_gpus": len(set(ids)) if on_gpu else 0,
+            "rccl_ranks": self.world if (self._collectives and self.info.backend == "nccl") else 0,
+        }
 
     def enable_p2p(self, max_floats: int, **kw) -> None:
         """Routes all_reduce_async of GPU buffers through the peer-to-peer kernel."""
