@@ -229,6 +229,19 @@ PYBIND11_MODULE(_hip, m) {
     P(p, float); P(g, const float); P(m, float); P(hyper, const float); V(n);
     fused_momentum_sgd(a, as_stream(stream));
   });
+  m.def("set_scalars", [](uint64_t f_dst, const std::vector<float>& f, uint64_t u_dst, const std::vector<uint64_t>& u,
+                          uint64_t stream) {
+    if (current_recorder()) throw std::runtime_error("set_scalars carries per-step values and cannot be recorded into a program");
+    if (f.size() > (size_t)kSetScalarsMax || u.size() > (size_t)kSetScalarsMax) throw std::runtime_error("set_scalars: at most 8 values of each kind");
+    SetScalarsArgs a{};
+    a.f_dst = reinterpret_cast<float*>(f_dst);
+    a.u_dst = reinterpret_cast<unsigned long long*>(u_dst);
+    a.nf = (int)f.size();
+    a.nu = (int)u.size();
+    for (int i = 0; i < a.nf; ++i) a.f[i] = f[i];
+    for (int i = 0; i < a.nu; ++i) a.u[i] = u[i];
+    set_scalars(a, as_stream(stream));
+  });
   m.def("flat_scale", [](const py::dict& d, uint64_t stream) {
     FlatScaleArgs a{};
     P(x, float); P(scale_dev, const float); a.scale = 1.f; V(scale); V(n);

@@ -118,6 +118,17 @@ struct FlatOptArgs {
 void fused_adam(const FlatOptArgs& a, hipStream_t stream);
 void fused_momentum_sgd(const FlatOptArgs& a, hipStream_t stream);
 
+// Writes up to 8 floats and up to 8 64-bit integers, passed BY VALUE, to device memory in stream
+// order: the step-dependent scalars of a replayed program (learning rate, gradient scale, step
+// counter) without a host staging buffer that a later step could overwrite before the copy ran.
+constexpr int kSetScalarsMax = 8;
+struct SetScalarsArgs {
+  float* f_dst; unsigned long long* u_dst;
+  float f[kSetScalarsMax]; unsigned long long u[kSetScalarsMax];
+  int nf, nu;
+};
+void set_scalars(const SetScalarsArgs& a, hipStream_t stream);
+
 // ---- elementwise / flat ---------------------------------------------------------------------
 struct FlatScaleArgs { float* x; const float* scale_dev; float scale; long long n; };
 void flat_scale(const FlatScaleArgs& a, hipStream_t stream);   // x *= (scale_dev ? *scale_dev : scale)

@@ -78,6 +78,14 @@ __global__ __launch_bounds__(256) void momentum_kernel(FlatOptArgs a) {
   }
 }
 
+// The values travel in the launch's own argument block, which the runtime copies when the launch
+// is enqueued: a later call cannot change what an earlier, not yet executed one will write.
+__global__ __launch_bounds__(64) void set_scalars_kernel(SetScalarsArgs a) {
+  const int t = threadIdx.x;
+  if (a.f_dst && t < a.nf) a.f_dst[t] = a.f[t];
+  if (a.u_dst && t < a.nu) a.u_dst[t] = a.u[t];
+}
+
 __global__ __launch_bounds__(256) void scale_kernel(FlatScaleArgs a) {
   const float s = a.scale_dev ? *a.scale_dev : a.scale;
   const long long n4 = a.n >> 2;
@@ -178,6 +186,11 @@ void fused_adam(const FlatOptArgs& a, hipStream_t stream) {
 }
 void fused_momentum_sgd(const FlatOptArgs& a, hipStream_t stream) {
   launch("fused_momentum_sgd", momentum_kernel, dim3(flat_blocks(a.n >> 2)), dim3(256), 0, stream, a);
+}
+void set_scalars(const SetScalarsArgs& a, hipStream_t stream) {
+  if (a.nf < 0 || a.nf > kSetScalarsMax || a.nu < 0 || a.nu > kSetScalarsMax) throw std::runtime_error("set_scalars: at most 8 values of each kind");
+  if ((a.nf > 0 && !a.f_dst) || (a.nu > 0 && !a.u_dst)) throw std::runtime_error("set_scalars: null destination");
+  launch("set_scalars", set_scalars_kernel, dim3(1), dim3(64), 0, stream, a);
 }
 void flat_scale(const FlatScaleArgs& a, hipStream_t stream) {
   launch("flat_scale", scale_kernel, dim3(flat_blocks(a.n >> 2)), dim3(256), 0, stream, a);

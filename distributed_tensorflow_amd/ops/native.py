@@ -650,6 +650,23 @@ def top1_count(logits, labels, correct):
 HYPER_SLOTS = 8  # lr_t, beta1, beta2, eps, grad_scale, momentum, weight_decay, spare
 
 
+def set_scalars(f_dst: Optional[torch.Tensor] = None, f_values=(), u_dst: Optional[torch.Tensor] = None, u_values=()) -> None:
+    """Stream-ordered write of a few scalars that are passed by value with the launch (no host
+    staging buffer): f_dst[:len(f_values)] = f_values (float32), u_dst[:len(u_values)] = u_values
+    (64-bit integers)."""
+    fp = up = 0
+    if f_dst is not None:
+        if f_dst.dtype != torch.float32 or not f_dst.is_cuda or f_dst.numel() < len(f_values):
+            raise ValueError("set_scalars: f_dst must be a float32 GPU tensor holding all values")
+        fp = f_dst.data_ptr()
+    if u_dst is not None:
+        if u_dst.dtype != torch.int64 or not u_dst.is_cuda or u_dst.numel() < len(u_values):
+            raise ValueError("set_scalars: u_dst must be an int64 GPU tensor holding all values")
+        up = u_dst.data_ptr()
+    _hip.set_scalars(fp, [float(x) for x in f_values] if fp else [], up, [int(x) & 0xFFFFFFFFFFFFFFFF for x in u_values] if up else [],
+                     stream())
+
+
 def fused_adam(p, g, m, v, hyper):
     require()
     n = p.numel()

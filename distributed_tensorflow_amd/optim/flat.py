@@ -35,12 +35,10 @@ class _FlatOptimizer:
 
             self._nv = nv
             self._hyper = torch.zeros(nv.HYPER_SLOTS, device=arena.params.device, dtype=torch.float32)
-            self._hyper_host = torch.zeros(nv.HYPER_SLOTS, dtype=torch.float32).pin_memory()
 
     def _stage(self, lr_t, beta1, beta2, eps, grad_scale, momentum, weight_decay) -> None:
-        h = self._hyper_host
-        h[0], h[1], h[2], h[3], h[4], h[5], h[6] = lr_t, beta1, beta2, eps, grad_scale, momentum, weight_decay
-        self._hyper.copy_(h, non_blocking=True)
+        # by value with the launch: steps queued without a host synchronisation keep their own values
+        self._nv.set_scalars(self._hyper, (lr_t, beta1, beta2, eps, grad_scale, momentum, weight_decay))
 
     def _range(self, lo: Optional[int], hi: Optional[int]) -> Tuple[int, int]:
         lo = 0 if lo is None else lo

@@ -29,9 +29,7 @@ class StepProgramBase:
         self._correct_buf = torch.zeros(self.SCALAR_SLOTS, device=dev, dtype=torch.int32)
         self.correct = self._correct_buf[0:1]
         self.hyper = torch.zeros(nv.HYPER_SLOTS, **f32)
-        self.hyper_host = torch.zeros(nv.HYPER_SLOTS, dtype=torch.float32).pin_memory()
         self.step_counter = torch.zeros(2, device=dev, dtype=torch.int64)
-        self.step_counter_host = torch.zeros(2, dtype=torch.int64).pin_memory()
         self.bucket_ranges: List[Tuple[int, int]] = []
         self.program = nv.hip().Program()
         self.num_segments = 1
@@ -63,15 +61,14 @@ class StepProgramBase:
     # ------------------------------------------------------------------------------------------
     def set_hyper(self, lr_t: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
                   grad_scale: float = 1.0, momentum: float = 0.9, weight_decay: float = 0.0) -> None:
-        """Stages the step-dependent scalars; ordered on the current stream before the next replay."""
-        h = self.hyper_host
-        h[0], h[1], h[2], h[3], h[4], h[5], h[6] = lr_t, beta1, beta2, eps, grad_scale, momentum, weight_decay
-        self.hyper.copy_(h, non_blocking=True)
+        """Writes the step-dependent scalars in stream order, before the next replay. The values
+        ride in the launch itself: the host may run any number of steps ahead of the GPU without
+        one step's values leaking into another's (a shared pinned staging buffer would allow that)."""
+        nv.set_scalars(self.hyper, (lr_t, beta1, beta2, eps, grad_scale, momentum, weight_decay))
 
     def set_step_counter(self, step: int) -> None:
         """Device-visible step number (dropout draws a fresh mask per step from it)."""
-        self.step_counter_host[0] = int(step) * (1 << 20)
-        self.step_counter.copy_(self.step_counter_host, non_blocking=True)
+        nv.set_scalars(u_dst=self.step_counter, u_values=(int(step) * (1 << 20),))
 
     def load_batch(self, images: torch.Tensor, labels: torch.Tensor) -> None:
         self.images.copy_(images.reshape(self.images.shape), non_blocking=True)

@@ -238,3 +238,43 @@ print("ok")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29717", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]
+
+
+def test_queued_steps_keep_their_own_scalars():
+    """Steps queued without any host synchronisation must each run with the learning rate and
+    gradient scale staged for them (the host runs far ahead of the GPU in the benchmark loop):
+    same parameters as a run that synchronises after every step."""
+    n, batch, steps = 1, 64, 24
+
+    def run(sync_each):
+        step, _, _ = _make(n, batch)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            step.instantiate()
+            for t in range(1, steps + 1):
+                # values that differ a lot from step to step, so a mix-up is visible
+                step.set_hyper(lr_t=ref.adam_lr_t(1e-3, t) * (1.0 + (t % 3)), grad_scale=1.0 / (1 + t % 4))
+                step.set_step_counter(t)
+                step.run(graph=True)
+                if sync_each:
+                    s.synchronize()
+        s.synchronize()
+        return step.arena.params.clone()
+
+    synced = run(True)
+    queued = run(False)
+    assert torch.equal(synced, queued)
+
+
+def test_set_scalars_values_travel_with_the_launch():
+    from distributed_tensorflow_amd.ops import native as nv
+
+    f = torch.zeros(8, device="cuda")
+    u = torch.zeros(2, device="cuda", dtype=torch.int64)
+    outs = []
+    for k in range(50):
+        nv.set_scalars(f, (k, 2 * k, 0.5), u, (k << 20,))
+        outs.append((f.clone(), u.clone()))          # stream-ordered snapshots, no host sync in between
+    torch.cuda.synchronize()
+    for k, (fo, uo) in enumerate(outs):
+        assert fo[:3].tolist() == [float(k), float(2 * k), 0.5] and int(uo[0]) == k << 20
