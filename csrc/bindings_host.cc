@@ -80,10 +80,12 @@ PYBIND11_MODULE(_host, m) {
 
   // ------------------------------------------------------------------ control board
   py::class_<Board>(m, "Board")
-      .def(py::init<const std::string&, int, bool>(), py::arg("name"), py::arg("world"), py::arg("create"))
+      .def(py::init<const std::string&, int, bool, uint64_t>(), py::arg("name"), py::arg("world"), py::arg("create"),
+           py::arg("nonce") = 0)
       .def_static("unlink", &Board::unlink)
       .def_static("now_ns", &Board::now_ns)
       .def_property_readonly("world", &Board::world)
+      .def_property_readonly("name", &Board::name)
       .def("mark_ready", &Board::mark_ready)
       .def("all_ready", &Board::all_ready)
       .def("wait_all_ready", [](Board& b, double t) { py::gil_scoped_release rel; return b.wait_all_ready(t); })
@@ -127,6 +129,49 @@ PYBIND11_MODULE(_host, m) {
       .def("ring_doorbell", &Board::ring_doorbell)
       .def("poll_doorbell", &Board::poll_doorbell)
       .def("clear_doorbell", &Board::clear_doorbell)
+      .def("request_save", &Board::request_save)
+      .def("save_step", &Board::save_step)
+      .def("agg_reset", &Board::agg_reset)
+      .def("agg_arrive", [](Board& b, int64_t e, int rank, int add, int quorum, int abort_at, float scale, bool any_update) {
+        Board::AggArrival r;
+        {
+          py::gil_scoped_release rel;
+          r = b.agg_arrive(e, rank, add, quorum, abort_at, scale, any_update);
+        }
+        return py::make_tuple(r.status, r.order, r.closed != 0, r.open_u);
+      }, py::arg("e"), py::arg("rank"), py::arg("add") = 1, py::arg("quorum") = 0, py::arg("abort_at") = 0,
+         py::arg("scale") = 0.f, py::arg("any_update") = false)
+      .def("agg_take_back", &Board::agg_take_back)
+      .def("agg_close", &Board::agg_close)
+      .def("agg_open_update", &Board::agg_open_update)
+      .def("agg_open_count", &Board::agg_open_count)
+      .def("agg_open_mask", &Board::agg_open_mask)
+      .def("agg_entry", [](const Board& b, int64_t u) -> py::object {
+        int count = 0;
+        uint32_t mask = 0, owners = 0;
+        float scale = 0.f;
+        bool rec = false;
+        if (!b.agg_entry(u, &count, &mask, &owners, &scale, &rec)) {
+          if (rec) throw std::runtime_error("update log: update " + std::to_string(u) + " was recycled (replica lags more than the ring)");
+          return py::none();
+        }
+        return py::make_tuple(count, mask, owners, scale);
+      })
+      .def("agg_wait_closed", [](const Board& b, int64_t u, double t) { py::gil_scoped_release rel; return b.agg_wait_closed(u, t); })
+      .def("agg_publish_ready", &Board::agg_publish_ready)
+      .def("agg_is_ready", &Board::agg_is_ready)
+      .def("agg_wait_ready", [](const Board& b, int64_t u, uint32_t owners, double t) {
+        py::gil_scoped_release rel;
+        return b.agg_wait_ready(u, owners, t);
+      })
+      .def("agg_set_applied", &Board::agg_set_applied)
+      .def("agg_applied", &Board::agg_applied)
+      .def("agg_min_applied", &Board::agg_min_applied)
+      .def("agg_wait_min_applied", [](const Board& b, int64_t v, double t) { py::gil_scoped_release rel; return b.agg_wait_min_applied(v, t); })
+      .def("agg_abort", &Board::agg_abort)
+      .def("agg_raise_abort", &Board::agg_raise_abort)
+      .def("agg_mark_dead", &Board::agg_mark_dead)
+      .def("agg_dead", &Board::agg_dead)
       .def("post_times", &Board::post_times)
       .def("get_times", [](const Board& b, int rank, int64_t iter) -> py::object {
         int64_t a = 0, c = 0;
@@ -135,4 +180,6 @@ PYBIND11_MODULE(_host, m) {
       });
   m.attr("BOARD_MAX_RANKS") = kBoardMaxRanks;
   m.attr("BOARD_RING") = kBoardRing;
+  m.attr("AGG_RING") = kAggRing;
+  m.attr("AGG_MAX_RANKS") = kAggMaxRanks;
 }

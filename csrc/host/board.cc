@@ -5,6 +5,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <limits>
@@ -29,7 +30,7 @@ int64_t Board::now_ns() {
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
 }
 
-Board::Board(const std::string& name, int world, bool create) : name_(name), owner_(create) {
+Board::Board(const std::string& name, int world, bool create, uint64_t nonce) : name_(name), owner_(create) {
   if (world < 1 || world > kBoardMaxRanks) throw std::runtime_error("Board: world size out of range");
   const std::string path = name[0] == '/' ? name : "/" + name;
   name_ = path;
@@ -39,17 +40,32 @@ Board::Board(const std::string& name, int world, bool create) : name_(name), own
     if (fd_ < 0) throw std::runtime_error("Board: shm_open(create) failed for " + path);
     if (::ftruncate(fd_, sizeof(BoardLayout)) != 0) throw std::runtime_error("Board: ftruncate failed");
   } else {
-    // The creator may still be setting up: retry briefly.
-    for (int i = 0; i < 2000 && fd_ < 0; ++i) {
+    // The creator may still be setting up, or the name may still point at the segment of an
+    // earlier run (killed before it could unlink): keep re-opening the NAME until the segment
+    // behind it is initialised and, when a nonce is given, stamped with it.
+    for (int attempt = 0; attempt < 6000; ++attempt) {
       fd_ = ::shm_open(path.c_str(), O_RDWR, 0600);
-      if (fd_ < 0) std::this_thread::sleep_for(std::chrono::milliseconds(5));
-    }
-    if (fd_ < 0) throw std::runtime_error("Board: shm_open(attach) failed for " + path);
-    struct stat st;
-    for (int i = 0; i < 2000; ++i) {
-      if (::fstat(fd_, &st) == 0 && (size_t)st.st_size >= sizeof(BoardLayout)) break;
+      if (fd_ >= 0) {
+        struct stat st;
+        if (::fstat(fd_, &st) == 0 && (size_t)st.st_size >= sizeof(BoardLayout)) {
+          void* q = ::mmap(nullptr, sizeof(BoardLayout), PROT_READ | PROT_WRITE, MAP_SHARED, fd_, 0);
+          if (q != MAP_FAILED) {
+            BoardLayout* l = static_cast<BoardLayout*>(q);
+            if (l->magic == kMagic && (nonce == 0 || l->nonce.load(std::memory_order_acquire) == nonce)) {
+              lay_ = l;
+              break;
+            }
+            ::munmap(q, sizeof(BoardLayout));
+          }
+        }
+        ::close(fd_);
+        fd_ = -1;
+      }
       std::this_thread::sleep_for(std::chrono::milliseconds(5));
     }
+    if (!lay_) throw std::runtime_error("Board: no initialised segment of this run found at " + path);
+    if (lay_->world != world) throw std::runtime_error("Board: world size mismatch with the creator");
+    return;
   }
   void* p = ::mmap(nullptr, sizeof(BoardLayout), PROT_READ | PROT_WRITE, MAP_SHARED, fd_, 0);
   if (p == MAP_FAILED) throw std::runtime_error("Board: mmap failed");
@@ -61,12 +77,10 @@ Board::Board(const std::string& name, int world, bool create) : name_(name), own
     for (auto& s : lay_->steps) s.tag.store(-1, std::memory_order_relaxed);
     for (auto& r : lay_->times)
       for (auto& t : r) t.iter.store(-1, std::memory_order_relaxed);
+    lay_->save_step.store(-1, std::memory_order_relaxed);
+    lay_->nonce.store(nonce, std::memory_order_relaxed);
     std::atomic_thread_fence(std::memory_order_release);
     lay_->magic = kMagic;
-  } else {
-    for (int i = 0; i < 4000 && lay_->magic != kMagic; ++i) std::this_thread::sleep_for(std::chrono::milliseconds(5));
-    if (lay_->magic != kMagic) throw std::runtime_error("Board: segment was never initialised");
-    if (lay_->world != world) throw std::runtime_error("Board: world size mismatch with the creator");
   }
 }
 
@@ -234,6 +248,180 @@ int64_t Board::poll_doorbell(int owner, int sender) const {
   return lay_->doorbell[owner][sender].load(std::memory_order_acquire) - 1;
 }
 void Board::clear_doorbell(int owner, int sender) { lay_->doorbell[owner][sender].store(0, std::memory_order_release); }
+
+// ---- checkpoint rendezvous --------------------------------------------------------------------------
+void Board::request_save(int64_t iteration) { lay_->save_step.store(iteration, std::memory_order_release); }
+int64_t Board::save_step() const { return lay_->save_step.load(std::memory_order_acquire); }
+
+// ---- update log ----------------------------------------------------------------------------------------
+namespace {
+constexpr uint64_t kFrozenBit = uint64_t(1) << 31;
+inline int64_t open_u(uint64_t w) { return int64_t(w >> 32); }
+inline int open_count(uint64_t w) { return int((w >> 16) & 0x7fff); }
+inline uint32_t open_mask(uint64_t w) { return uint32_t(w & 0xffff); }
+inline uint64_t make_open(int64_t u, int count, uint32_t mask, bool frozen) {
+  return (uint64_t(u) << 32) | (frozen ? kFrozenBit : 0) | (uint64_t(count & 0x7fff) << 16) | (mask & 0xffff);
+}
+inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+}  // namespace
+
+void Board::agg_reset(int64_t u0) {
+  for (auto& e : lay_->agg_hist) {
+    e.tag.store(0, std::memory_order_relaxed);
+    for (auto& r : e.ready) r.store(0, std::memory_order_relaxed);
+  }
+  for (auto& a : lay_->agg_applied) a.store(u0, std::memory_order_relaxed);
+  lay_->agg_abort.store(0, std::memory_order_relaxed);
+  lay_->agg_dead.store(0, std::memory_order_relaxed);
+  lay_->agg_open.store(make_open(u0, 0, 0, false), std::memory_order_release);
+}
+
+// Publishes the record of update u (contributors, owners, scale) and opens u+1. Called by exactly
+// one thread: the one whose compare-exchange set the frozen bit.
+static void publish_closed(BoardLayout* lay, int64_t u, int count, uint32_t mask, uint32_t owners, float scale) {
+  BoardAggEntry& h = lay->agg_hist[u % kAggRing];
+  h.tag.store(0, std::memory_order_release);
+  for (auto& r : h.ready) r.store(0, std::memory_order_relaxed);
+  h.owners.store(owners, std::memory_order_relaxed);
+  h.scale_bits.store(f2u(scale), std::memory_order_relaxed);
+  h.tag.store((uint64_t(u + 1) << 32) | (uint64_t(count & 0xffff) << 16) | (mask & 0xffff), std::memory_order_release);
+  lay->agg_open.store(make_open(u + 1, 0, 0, false), std::memory_order_release);
+}
+
+Board::AggArrival Board::agg_arrive(int64_t e, int rank, int add, int quorum, int abort_at, float scale, bool any_update) {
+  if (rank < 0 || rank >= kAggMaxRanks) throw std::runtime_error("Board: the update log serves at most 16 replicas");
+  AggArrival r{0, 0, 0, 0};
+  uint64_t w = lay_->agg_open.load(std::memory_order_acquire);
+  for (int spins = 0;; ++spins) {
+    const int64_t u = open_u(w);
+    r.open_u = u;
+    if (!any_update && u != e) {
+      r.status = 1;   // an update other than e is open: the gradient was computed on parameters that are no longer current
+      return r;
+    }
+    if (w & kFrozenBit) {
+      if (!any_update) {   // quorum complete, the closer is publishing: too late for e
+        r.status = 2;
+        return r;
+      }
+      relax(spins);        // interval mode: wait for the next window to open
+      w = lay_->agg_open.load(std::memory_order_acquire);
+      continue;
+    }
+    const int c = open_count(w), c2 = c + add;
+    const uint32_t m2 = open_mask(w) | (1u << rank);
+    const bool closes = quorum > 0 && c2 >= quorum;
+    if (lay_->agg_open.compare_exchange_weak(w, make_open(u, c2, m2, closes), std::memory_order_acq_rel)) {
+      r.order = c;
+      if (abort_at > 0 && c2 >= abort_at) agg_raise_abort(u + 1);
+      if (closes) {
+        r.closed = 1;
+        publish_closed(lay_, u, c2, m2, m2, scale > 0.f ? scale : 1.f / float(c2));
+        r.open_u = u + 1;
+      }
+      return r;
+    }
+  }
+}
+
+bool Board::agg_take_back(int64_t e, int rank, int count) {
+  uint64_t w = lay_->agg_open.load(std::memory_order_acquire);
+  for (;;) {
+    if (open_u(w) != e || (w & kFrozenBit) || !(open_mask(w) & (1u << rank)) || open_count(w) < count) return false;
+    if (lay_->agg_open.compare_exchange_weak(w, make_open(e, open_count(w) - count, open_mask(w) & ~(1u << rank), false),
+                                             std::memory_order_acq_rel))
+      return true;
+  }
+}
+
+int64_t Board::agg_close(int owner_rank) {
+  uint64_t w = lay_->agg_open.load(std::memory_order_acquire);
+  for (;;) {
+    if ((w & kFrozenBit) || open_count(w) < 1) return -1;
+    if (lay_->agg_open.compare_exchange_weak(w, w | kFrozenBit, std::memory_order_acq_rel)) break;
+  }
+  const int64_t u = open_u(w);
+  publish_closed(lay_, u, open_count(w), open_mask(w), 1u << owner_rank, 1.f / float(open_count(w)));
+  return u;
+}
+
+int64_t Board::agg_open_update() const { return open_u(lay_->agg_open.load(std::memory_order_acquire)); }
+int Board::agg_open_count() const { return open_count(lay_->agg_open.load(std::memory_order_acquire)); }
+uint32_t Board::agg_open_mask() const { return open_mask(lay_->agg_open.load(std::memory_order_acquire)); }
+
+bool Board::agg_entry(int64_t u, int* count, uint32_t* mask, uint32_t* owners, float* scale, bool* recycled) const {
+  const BoardAggEntry& h = lay_->agg_hist[u % kAggRing];
+  const uint64_t t = h.tag.load(std::memory_order_acquire);
+  const int64_t tu = int64_t(t >> 32) - 1;
+  if (recycled) *recycled = tu > u;
+  if (tu != u) return false;
+  const uint32_t ow = h.owners.load(std::memory_order_relaxed);
+  const uint32_t sb = h.scale_bits.load(std::memory_order_relaxed);
+  if (h.tag.load(std::memory_order_acquire) != t) {   // recycled while reading
+    if (recycled) *recycled = true;
+    return false;
+  }
+  if (count) *count = int((t >> 16) & 0xffff);
+  if (mask) *mask = uint32_t(t & 0xffff);
+  if (owners) *owners = ow;
+  if (scale) *scale = u2f(sb);
+  return true;
+}
+
+bool Board::agg_wait_closed(int64_t u, double timeout_s) const {
+  const int64_t deadline = now_ns() + int64_t(timeout_s * 1e9);
+  for (int spins = 0;; ++spins) {
+    bool rec = false;
+    if (agg_entry(u, nullptr, nullptr, nullptr, nullptr, &rec) || rec) return true;
+    if (should_stop() || now_ns() > deadline) return false;
+    relax(spins);
+  }
+}
+
+void Board::agg_publish_ready(int64_t u, int owner) {
+  lay_->agg_hist[u % kAggRing].ready[owner].store(u + 1, std::memory_order_release);
+}
+bool Board::agg_is_ready(int64_t u, int owner) const {
+  return lay_->agg_hist[u % kAggRing].ready[owner].load(std::memory_order_acquire) >= u + 1;
+}
+bool Board::agg_wait_ready(int64_t u, uint32_t owners, double timeout_s) const {
+  const int64_t deadline = now_ns() + int64_t(timeout_s * 1e9);
+  for (int spins = 0;; ++spins) {
+    bool all = true;
+    for (int p = 0; p < kAggMaxRanks; ++p)
+      if ((owners >> p) & 1u) all = all && agg_is_ready(u, p);
+    if (all) return true;
+    if (should_stop() || now_ns() > deadline) return false;
+    relax(spins);
+  }
+}
+
+void Board::agg_set_applied(int rank, int64_t version) { lay_->agg_applied[rank].store(version, std::memory_order_release); }
+int64_t Board::agg_applied(int rank) const { return lay_->agg_applied[rank].load(std::memory_order_acquire); }
+int64_t Board::agg_min_applied() const {
+  const uint32_t dead = lay_->agg_dead.load(std::memory_order_acquire);
+  int64_t m = std::numeric_limits<int64_t>::max();
+  for (int r = 0; r < lay_->world && r < kAggMaxRanks; ++r)
+    if (!((dead >> r) & 1u)) m = std::min(m, agg_applied(r));
+  return m;
+}
+bool Board::agg_wait_min_applied(int64_t version, double timeout_s) const {
+  const int64_t deadline = now_ns() + int64_t(timeout_s * 1e9);
+  for (int spins = 0; agg_min_applied() < version; ++spins) {
+    if (should_stop() || now_ns() > deadline) return false;
+    relax(spins);
+  }
+  return true;
+}
+int64_t Board::agg_abort() const { return lay_->agg_abort.load(std::memory_order_acquire); }
+void Board::agg_raise_abort(int64_t value) {
+  int64_t cur = lay_->agg_abort.load(std::memory_order_relaxed);
+  while (cur < value && !lay_->agg_abort.compare_exchange_weak(cur, value, std::memory_order_acq_rel)) {
+  }
+}
+void Board::agg_mark_dead(int rank) { lay_->agg_dead.fetch_or(1u << rank, std::memory_order_acq_rel); }
+uint32_t Board::agg_dead() const { return lay_->agg_dead.load(std::memory_order_acquire); }
 
 // ---- telemetry -------------------------------------------------------------------------------------------
 void Board::post_times(int rank, int64_t iter, int64_t t_dequeue_ns, int64_t t_finish_ns) {

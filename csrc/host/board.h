@@ -25,6 +25,8 @@ namespace dtf {
 constexpr int kBoardMaxRanks = 64;
 constexpr int kBoardRing = 64;
 constexpr int kBoardTimeRing = 1024;
+constexpr int kAggRing = 16;       // closed updates kept for replicas that lag behind
+constexpr int kAggMaxRanks = 16;   // width of the contributor / owner masks of the update log
 
 struct BoardStepSlot {
   std::atomic<int64_t> tag;          // step this slot currently serves (-1 = free)
@@ -42,10 +44,26 @@ struct BoardTimeRec {
   std::atomic<int64_t> t_finish_ns;
 };
 
+// One closed update of the aggregation log (see the "update log" block in class Board).
+struct BoardAggEntry {
+  std::atomic<uint64_t> tag;       // (u+1)<<32 | count<<16 | contributor mask; 0 = never closed
+  std::atomic<uint32_t> owners;    // replicas that hold a reduced shard of this update
+  std::atomic<uint32_t> scale_bits;  // float: what the reduced SUM is multiplied by (1/M, 1/count, 1/sum of weights)
+  std::atomic<int64_t> ready[kAggMaxRanks];   // ready[p] = u+1 once owner p has published its reduced shard
+};
+
 struct BoardLayout {
   uint64_t magic;
   int32_t world;
   int32_t version;
+  std::atomic<uint64_t> nonce;                      // identifies the run that created the segment
+  std::atomic<int64_t> save_step;                   // iteration at which every replica joins a checkpoint gather (-1 = none)
+  // update log
+  std::atomic<uint64_t> agg_open;                   // u<<32 | frozen<<31 | count<<16 | contributor mask
+  std::atomic<int64_t> agg_abort;                   // e+1 once update e has all the gradients it will take
+  std::atomic<int64_t> agg_applied[kAggMaxRanks];   // version (updates applied) of every replica
+  std::atomic<uint32_t> agg_dead;                   // replicas the watchdog has given up on
+  BoardAggEntry agg_hist[kAggRing];
   std::atomic<int64_t> global_step;
   std::atomic<int32_t> should_stop;
   std::atomic<int32_t> generation;                  // bumped by barriers
@@ -65,7 +83,9 @@ struct BoardLayout {
 class Board {
  public:
   // Creates (rank 0 / create=true) or attaches to the named segment.
-  Board(const std::string& name, int world, bool create);
+  // nonce != 0: the creator stamps it into the segment and an attacher keeps re-opening the name
+  // until it finds that stamp (a segment left behind by an earlier run carries another one).
+  Board(const std::string& name, int world, bool create, uint64_t nonce = 0);
   ~Board();
   Board(const Board&) = delete;
   Board& operator=(const Board&) = delete;
@@ -74,6 +94,7 @@ class Board {
   static int64_t now_ns();
 
   int world() const { return lay_->world; }
+  const std::string& name() const { return name_; }
 
   // ---- startup barrier (reference: timeout_manager.py launch_manager spin-until-all-ready)
   void mark_ready(int rank);
@@ -125,6 +146,52 @@ class Board {
   bool ring_doorbell(int owner, int sender, int64_t local_step);   // false if the previous push is still pending
   int64_t poll_doorbell(int owner, int sender) const;              // -1 if empty, else local_step
   void clear_doorbell(int owner, int sender);
+
+  // ---- checkpoint rendezvous (sharded optimizer state must be gathered by all replicas at the
+  // same iteration; the chief announces the iteration two steps ahead)
+  void request_save(int64_t iteration);
+  int64_t save_step() const;
+
+  // ---- update log: non-blocking aggregation (backup workers, interval, soft-kill, weighted).
+  // Replicas apply the same sequence of reduced gradients ("updates"). Update u is OPEN while
+  // gradients computed on version u arrive; it is CLOSED by the arrival that completes the quorum
+  // or by the chief's interval timer; a closed update records who contributed, who holds the
+  // reduced shards and the scale, and stays readable for kAggRing updates so that a replica that
+  // was not waiting (a straggler) can apply it later. Nobody ever waits for a non-contributor.
+  struct AggArrival {
+    int status;      // 0 = accepted, 1 = stale (update e is already closed), 2 = late (quorum already full)
+    int order;       // gradients accepted before this one (status 0)
+    int closed;      // 1 if this arrival completed the quorum and closed the update
+    int64_t open_u;  // update that was open when the call returned
+  };
+  void agg_reset(int64_t u0);
+  // Registers `add` gradients of replica `rank` for update e. quorum > 0: the arrival that brings
+  // the count to quorum closes the update (owners = contributors, scale as given, or 1/count when
+  // scale <= 0); abort_at > 0: the abort word is raised to e+1 when the count reaches it.
+  // any_update: accept whatever update is open (interval mode) instead of only e.
+  AggArrival agg_arrive(int64_t e, int rank, int add, int quorum, int abort_at, float scale, bool any_update);
+  // Interval mode: withdraws this replica's pending contribution from the still-open update e.
+  bool agg_take_back(int64_t e, int rank, int count);
+  // Chief timer: closes the open update if it holds at least one gradient; the closer owns the
+  // whole reduced vector. Returns the closed update or -1.
+  int64_t agg_close(int owner_rank);
+  int64_t agg_open_update() const;
+  int agg_open_count() const;
+  uint32_t agg_open_mask() const;
+  // Closed-update record; false while update u is not closed (or already recycled: *recycled).
+  bool agg_entry(int64_t u, int* count, uint32_t* mask, uint32_t* owners, float* scale, bool* recycled) const;
+  bool agg_wait_closed(int64_t u, double timeout_s) const;
+  void agg_publish_ready(int64_t u, int owner);
+  bool agg_is_ready(int64_t u, int owner) const;
+  bool agg_wait_ready(int64_t u, uint32_t owners, double timeout_s) const;
+  void agg_set_applied(int rank, int64_t version);
+  int64_t agg_applied(int rank) const;
+  int64_t agg_min_applied() const;   // over replicas not marked dead
+  bool agg_wait_min_applied(int64_t version, double timeout_s) const;
+  int64_t agg_abort() const;
+  void agg_raise_abort(int64_t value);
+  void agg_mark_dead(int rank);
+  uint32_t agg_dead() const;
 
   // ---- timing telemetry
   void post_times(int rank, int64_t iter, int64_t t_dequeue_ns, int64_t t_finish_ns);

@@ -230,6 +230,8 @@ def define_extension_flags() -> None:
     DEFINE_float("momentum", 0.9, "Momentum of the momentum-SGD optimizer")
     DEFINE_string("device", "auto", "auto, cuda or cpu")
     DEFINE_boolean("async_method", False, "Asynchronous SGD over staleness-bounded parameter shards")
+    DEFINE_integer("interval_max_staleness", -1, "Interval mode: drop a gradient computed on parameters more than this many "
+                   "updates old (-1: accept any, the gradient counts for the window that is open when it is pushed, like the reference)")
     DEFINE_integer("staleness_bound", 4, "Async mode: gradients older than this many updates are dropped")
     DEFINE_boolean("weighted_grads_method", False, "Least-squares weighted gradient aggregation with simulated worker kills")
     DEFINE_integer("grad_buckets", 0, "Gradient all-reduce buckets overlapped with the backward pass (0: three for the "

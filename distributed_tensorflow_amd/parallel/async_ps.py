@@ -86,7 +86,7 @@ class AsyncParameterShards:
                 _shm_tensor(self._files[-1], n_own, True)
             self._files.append(f"{self._name}_shard_{self.rank}")
             own = _shm_tensor(self._files[-1], n_own, True)
-            own.copy_(self.arena.params[lo:hi])
+            own.copy_(self.arena.full("params")[lo:hi])
             self.comm.barrier()
             self.shards = []
             self.inboxes: List[List[torch.Tensor]] = []
@@ -102,7 +102,7 @@ class AsyncParameterShards:
         dev = self.arena.params.device
         own_shard = torch.empty(max(1, n_own), device=dev, dtype=torch.float32)
         lo, hi = self.bounds[self.rank]
-        own_shard[:n_own].copy_(self.arena.params[lo:hi])
+        own_shard[:n_own].copy_(self.arena.full("params")[lo:hi])
         own_inbox = [torch.zeros(max(1, n_own), device=dev, dtype=torch.float32) for _ in range(self.world)]
         torch.cuda.synchronize()
         self._own_keepalive = (own_shard, own_inbox)
@@ -123,7 +123,7 @@ class AsyncParameterShards:
     # ------------------------------------------------------------------------------------------
     def pull(self) -> None:
         """One-sided read of every shard into the local parameter arena."""
-        p = self.arena.params
+        p = self.arena.full("params")
         with self.replica.stream_ctx():
             for o, (lo, hi) in enumerate(self.bounds):
                 self._pulled_version[o] = self.board.shard_version(o)
@@ -133,7 +133,7 @@ class AsyncParameterShards:
 
     def push(self) -> None:
         """One-sided write of each gradient slice into its owner's inbox + doorbell."""
-        g = self.arena.grads
+        g = self.arena.full("grads")
         for k in range(self.world):
             o = (self.rank + k) % self.world  # start with the own shard, spread the peers
             lo, hi = self.bounds[o]
@@ -192,15 +192,15 @@ class AsyncParameterShards:
                     [ref.adam_lr_t(lr, version + 1) if opt == "adam" else lr, 0.9, 0.999, 1e-8, 1.0,
                      self.replica.momentum, self.replica.weight_decay, 0.0], dtype=torch.float32).to(grad.device)
                 if opt == "adam":
-                    nv.fused_adam(shard, grad, a.slots["m"][lo:hi], a.slots["v"][lo:hi], hyper)
+                    nv.fused_adam(shard, grad, a.full("slot:m")[lo:hi], a.full("slot:v")[lo:hi], hyper)
                 else:
-                    nv.fused_momentum_sgd(shard, grad, a.slots["m"][lo:hi], hyper)
+                    nv.fused_momentum_sgd(shard, grad, a.full("slot:m")[lo:hi], hyper)
             self.replica.synchronize()
         else:
             if opt == "adam":
-                ref.adam_update(shard, grad, a.slots["m"][lo:hi], a.slots["v"][lo:hi], ref.adam_lr_t(lr, version + 1))
+                ref.adam_update(shard, grad, a.full("slot:m")[lo:hi], a.full("slot:v")[lo:hi], ref.adam_lr_t(lr, version + 1))
             else:
-                ref.momentum_update(shard, grad, a.slots["m"][lo:hi], lr, self.replica.momentum, self.replica.weight_decay)
+                ref.momentum_update(shard, grad, a.full("slot:m")[lo:hi], lr, self.replica.momentum, self.replica.weight_decay)
 
     # ------------------------------------------------------------------------------------------
     def step(self) -> Tuple[float, int]:

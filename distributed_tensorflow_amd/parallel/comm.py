@@ -16,7 +16,7 @@ from __future__ import annotations
 import datetime
 import os
 from dataclasses import dataclass
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional
 
 import torch
 import torch.distributed as dist
@@ -67,6 +67,7 @@ class Communicator:
         # forced on (from_env(force_group=True)) to run the real backend's code path on one GPU.
         self._collectives = info.world > 1 if collectives is None else collectives
         self._pending: List = []
+        self.collectives_issued = 0   # data-plane collectives started by this rank (tests count them per step)
         self.p2p = None   # optional hand-written peer-to-peer all-reduce (parallel/p2p.py)
 
     # -- construction ----------------------------------------------------------------------------
@@ -127,6 +128,7 @@ class Communicator:
         current stream, so later kernels on the current stream overlap with it."""
         if not self._collectives:
             return
+        self.collectives_issued += 1
         if self.p2p is not None and flat.is_cuda:
             self.p2p.all_reduce(flat)   # stream-ordered kernel on the current stream
             return
@@ -148,6 +150,7 @@ class Communicator:
         if self.p2p is not None or not flat.is_cuda or self.info.backend != "nccl":
             self.all_reduce_async(flat)
             return
+        self.collectives_issued += 1
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
 
     def wait_all(self) -> None:
@@ -161,40 +164,50 @@ class Communicator:
             dist.all_reduce(t, op=op)
         return t
 
-    def reduce_scatter_flat(self, flat: torch.Tensor, bounds: Sequence[Tuple[int, int]]) -> torch.Tensor:
-        """Reduce-scatter over uneven contiguous shards: rank r ends up with the SUM of
-        flat[bounds[r]] (returned as a view of `flat`)."""
-        lo, hi = bounds[self.rank]
+    def reduce_scatter_flat(self, flat: torch.Tensor, shard: int) -> torch.Tensor:
+        """ONE reduce-scatter over `world` equal contiguous shards of `shard` floats: rank r ends up
+        with the SUM of flat[r*shard:(r+1)*shard] in place (returned as a view of `flat`, which is
+        the arena's padded buffer, ParamArena.padded)."""
+        lo, hi = self.rank * shard, (self.rank + 1) * shard
+        if flat.numel() != shard * self.world:
+            raise ValueError("reduce_scatter_flat: the buffer must hold exactly `world` shards")
         if not self._collectives:
             return flat[lo:hi]
+        self.collectives_issued += 1
         if flat.is_cuda and self.info.backend == "gloo":
             torch.cuda.current_stream().synchronize()
             host = flat.detach().cpu()
-            self.reduce_scatter_flat(host, bounds)
-            flat[lo:hi].copy_(host[lo:hi])
+            out = torch.empty(shard, dtype=flat.dtype)
+            dist.reduce_scatter_tensor(out, host, op=dist.ReduceOp.SUM)
+            flat[lo:hi].copy_(out)
             return flat[lo:hi]
-        sizes = {b[1] - b[0] for b in bounds}
-        if len(sizes) == 1 and self.info.backend == "nccl":
-            dist.reduce_scatter_tensor(flat[lo:hi], flat[: bounds[-1][1]], op=dist.ReduceOp.SUM)
+        if self.info.backend == "nccl":
+            dist.reduce_scatter_tensor(flat[lo:hi], flat, op=dist.ReduceOp.SUM)   # in place: output = own chunk of the input
         else:
-            works = [dist.reduce(flat[b[0]:b[1]], dst=r, op=dist.ReduceOp.SUM, async_op=True) for r, b in enumerate(bounds)]
-            for w in works:
-                w.wait()
+            out = torch.empty(shard, dtype=flat.dtype, device=flat.device)
+            dist.reduce_scatter_tensor(out, flat, op=dist.ReduceOp.SUM)
+            flat[lo:hi].copy_(out)
         return flat[lo:hi]
 
-    def all_gather_flat(self, flat: torch.Tensor, bounds: Sequence[Tuple[int, int]]) -> None:
-        """Every rank broadcasts its shard flat[bounds[rank]] into the same range on all ranks."""
+    def all_gather_flat(self, flat: torch.Tensor, shard: int) -> None:
+        """ONE all-gather: every rank contributes flat[rank*shard:(rank+1)*shard] and receives all
+        shards in place."""
+        lo, hi = self.rank * shard, (self.rank + 1) * shard
+        if flat.numel() != shard * self.world:
+            raise ValueError("all_gather_flat: the buffer must hold exactly `world` shards")
         if not self._collectives:
             return
+        self.collectives_issued += 1
         if flat.is_cuda and self.info.backend == "gloo":
             torch.cuda.current_stream().synchronize()
             host = flat.detach().cpu()
-            self.all_gather_flat(host, bounds)
+            dist.all_gather_into_tensor(host, host[lo:hi].clone())
             flat.copy_(host)
             return
-        works = [dist.broadcast(flat[b[0]:b[1]], src=r, async_op=True) for r, b in enumerate(bounds)]
-        for w in works:
-            w.wait()
+        if self.info.backend == "nccl":
+            dist.all_gather_into_tensor(flat, flat[lo:hi])   # in place: input = own chunk of the output
+        else:
+            dist.all_gather_into_tensor(flat, flat[lo:hi].clone())
 
     def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         if self._collectives:

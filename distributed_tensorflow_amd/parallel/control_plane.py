@@ -30,11 +30,40 @@ def board_name_for(train_dir: str, port: int) -> str:
     return f"dtf_{base}_{port}_{os.getuid()}"
 
 
-def open_board(name: str, world: int, rank: int):
-    """Rank 0 creates the segment, the others attach."""
+def open_board(name: str, world: int, rank: int, nonce: int = 0):
+    """Rank 0 creates the segment, the others attach. With a nonce (any value all ranks of THIS run
+    agree on) an attacher ignores a segment of the same name left behind by an earlier run."""
     from .. import _host
 
-    return _host.Board(name, world, rank == 0)
+    return _host.Board(name, world, rank == 0, nonce)
+
+
+def run_nonce(comm) -> int:
+    """A value unique to this run, agreed by all ranks through the process group."""
+    import random
+
+    mine = random.SystemRandom().getrandbits(62) | 1
+    return int(comm.all_gather_object(mine)[0])
+
+
+def unlink_on_sigterm(name: str) -> None:
+    """The launcher stops workers with SIGTERM, which skips destructors: remove the segment first,
+    then let the default action end the process."""
+    import signal
+
+    from .. import _host
+
+    def handler(signum, frame):
+        try:
+            _host.Board.unlink(name)
+        finally:
+            signal.signal(signum, signal.SIG_DFL)
+            os.kill(os.getpid(), signum)
+
+    try:
+        signal.signal(signal.SIGTERM, handler)
+    except ValueError:
+        pass   # not the main thread
 
 
 class TimeoutClient:

@@ -1,22 +1,27 @@
 """Gradient-aggregation policies: what the reference implements as TensorFlow optimizer wrappers
-around parameter-server accumulators and token queues, re-expressed over collectives.
+around parameter-server accumulators and token queues, re-expressed without a parameter server.
 
-Every policy ends a step with ALL replicas holding identical parameters: each replica runs the
-same fused optimizer on the same aggregated gradient, so no parameter broadcast is needed.
+Every policy keeps ALL replicas' parameters identical: each replica runs the same fused optimizer
+on the same aggregated gradients in the same order, so no parameter broadcast is needed.
 
   FullSync      tf.train.SyncReplicasOptimizer(V2): mean of all N gradients
-                (reference: DistributedLeNet/src/distributed_train.py:181-185).
-  Backup(M)     BackupOptimizer: mean of the first M gradients of the step, the other N-M are
-                dropped, everybody advances (reference: backup_worker_optimizer.py:163,241-307).
-                Realised as a MASKED all-reduce: arrival order comes from one atomic fetch-add on
-                the shared-memory board; a replica whose order >= M contributes zeros; stragglers
-                still computing when the M-th gradient lands short-circuit their backward pass so
-                the collective is not held up by them; divisor M.
-  Interval(ms)  TimeoutReplicasOptimizer.start_interval_updates: the update uses whatever arrived
-                within `interval_ms` of the step opening (reference:
-                DistributedResNet/src/sync_replicas_optimizer_modified/sync_replicas_optimizer_modified.py:207-214,402-410);
-                late replicas short-circuit and contribute zeros; divisor = number in time
-                (carried through the same collective); no gradient in time = no update.
+                (reference: DistributedLeNet/src/distributed_train.py:181-185): bucketed all-reduce
+                overlapped with backward, or reduce-scatter + per-shard optimizer + all-gather.
+The straggler policies run on the update log (parallel/update_log.py: a replicated log of reduced
+gradients; nobody waits for a replica whose gradient is not part of the update):
+  Backup(M)     BackupOptimizer: the update fires as soon as M gradients of the current version
+                are in (arrival order = one compare-exchange), is the mean of those M, and releases
+                everybody; a straggler's late gradient is dropped, the straggler applies the
+                update(s) it missed and goes on with fresh parameters
+                (reference: backup_worker_optimizer.py:163,241-307). Stragglers still computing
+                when the M-th gradient lands short-circuit the rest of their backward pass.
+  Interval(ms)  TimeoutReplicasOptimizer.start_interval_updates: a timer on the chief closes a
+                window every `interval_ms` and applies the mean of whatever was pushed into it;
+                workers push and go on, they never wait (reference:
+                DistributedResNet/src/sync_replicas_optimizer_modified/sync_replicas_optimizer_modified.py:207-214,402-430).
+                A gradient is tagged with the window that is open when it is pushed, as in the
+                reference (local_step is re-read at push time, :293,339); `max_staleness` >= 0 drops
+                gradients computed on parameters older than that many updates instead.
   SoftKill(k)   SoftKillOptimizer + short-circuited gradients: once k gradients have arrived the
                 remaining replicas stop back-propagating and push zeros for the layers not yet
                 done (reference: soft_kill_optimizer.py:424-442, short_circuit_gradients.py:487-545);
@@ -28,43 +33,68 @@ The asynchronous policy lives in parallel/async_ps.py.
 """
 from __future__ import annotations
 
+import threading
 import time
 from dataclasses import dataclass
-from typing import List
+from typing import List, Optional
 
 import numpy as np
 
 from .comm import Communicator
+from .update_log import LrLike, lr_at
 
 
 @dataclass
 class StepResult:
-    applied: bool            # parameters were updated
-    contributors: int        # gradients that entered the update
+    applied: bool            # parameters were updated during this call
+    contributors: int        # gradients that entered the (last) update
     aborted: bool            # this replica short-circuited its backward pass
-    included: bool           # this replica's gradient was part of the update
+    included: bool           # this replica's gradient was part of an update
     compute_s: float = 0.0   # time from step start to gradients ready on this replica
+    global_step: Optional[int] = None   # updates applied so far (None: one more than before iff `applied`)
 
 
 class Strategy:
     name = "base"
     needs_abort_points = False
+    uses_update_log = False
 
     def __init__(self, comm: Communicator, board=None):
         self.comm = comm
         self.board = board
         self.world = comm.world
         self.rank = comm.rank
+        self.log = None
+        self.start_version = 0   # set by the driver after a checkpoint restore, before the first step
 
-    def step(self, replica, step: int, lr: float) -> StepResult:  # pragma: no cover - interface
+    def step(self, replica, step: int, lr: LrLike) -> StepResult:  # pragma: no cover - interface
         raise NotImplementedError
 
+    def finish(self) -> None:
+        """End of training (all replicas call it): keeps published data reachable until every
+        live replica has caught up, then releases it."""
+        if self.log is not None:
+            self.log.finish()
+            self.comm.barrier()
+            self.log.close()
+            self.log = None
+
     # helpers --------------------------------------------------------------------------------------
-    def _allreduce_full(self, replica, with_aux: bool = False) -> None:
-        a = replica.arena
-        with replica.stream_ctx():   # collectives order against the replica's compute stream
-            self.comm.all_reduce_inline(a.grads_full if with_aux else a.grads)
+    def _get_log(self, replica):
+        if self.log is None:
+            from .update_log import make_update_log
+
+            self.log = make_update_log(replica, self.comm, self.board, self.start_version)
+        return self.log
+
+    def _plain_step(self, replica, lr: LrLike, t0: float) -> StepResult:
+        """One replica, or nothing to drop: forward + backward + (all-reduce) + update."""
+        replica.forward_backward(on_bucket=self._bucket_reduce(replica))
+        dt = time.time() - t0
+        with replica.stream_ctx():
             self.comm.wait_all()
+        replica.apply_update(lr_at(lr, replica.updates_applied), grad_scale=1.0 / self.world)
+        return StepResult(True, self.world, False, True, dt, replica.updates_applied)
 
     def _bucket_reduce(self, replica):
         """Callback for forward_backward(on_bucket=...): buckets become final from the end of the
@@ -87,140 +117,152 @@ class FullSync(Strategy):
         super().__init__(comm, board)
         self.reduce_scatter = reduce_scatter
 
-    def step(self, replica, step: int, lr: float) -> StepResult:
+    def step(self, replica, step: int, lr: LrLike) -> StepResult:
         t0 = time.time()
         if self.reduce_scatter and self.world > 1:
-            return self._step_sharded(replica, lr, t0)
-        replica.forward_backward(on_bucket=self._bucket_reduce(replica))
-        dt = time.time() - t0
-        with replica.stream_ctx():
-            self.comm.wait_all()
-        replica.apply_update(lr, grad_scale=1.0 / self.world)
-        return StepResult(True, self.world, False, True, dt)
+            return self._step_sharded(replica, lr_at(lr, replica.updates_applied), t0)
+        return self._plain_step(replica, lr, t0)
 
     def _step_sharded(self, replica, lr: float, t0: float) -> StepResult:
-        """Reduce-scatter + sharded optimizer + all-gather: every rank owns a contiguous 1/N of
-        the parameters and of the optimizer slots, reduces only that range of the gradient,
-        updates it, and the updated ranges are gathered back. Moves the same bytes as the
-        all-reduce but the optimizer reads 1/N of the state per rank; it is also the layout of
-        the asynchronous parameter shards (parallel/async_ps.py)."""
+        """Reduce-scatter + sharded optimizer + all-gather, ONE collective each way: every rank
+        owns an equal contiguous 1/N of the (padded) parameter and optimizer-slot buffers, reduces
+        only that range of the gradient, updates it, and the updated ranges are gathered back.
+        Moves the same bytes as the all-reduce but the optimizer reads 1/N of the state per rank;
+        it is also the layout of the asynchronous parameter shards (parallel/async_ps.py)."""
         a = replica.arena
-        bounds = a.shard_bounds(self.world)
+        shard = a.shard_size(self.world)
         replica.forward_backward()
         dt = time.time() - t0
-        lo, hi = bounds[self.rank]
+        lo, hi = self.rank * shard, (self.rank + 1) * shard
         with replica.stream_ctx():
-            self.comm.reduce_scatter_flat(a.grads, bounds)
+            self.comm.reduce_scatter_flat(a.padded("grads", self.world), shard)
         replica.apply_update_shard(lr, 1.0 / self.world, lo, hi)
         with replica.stream_ctx():
-            self.comm.all_gather_flat(a.params, bounds)
-        return StepResult(True, self.world, False, True, dt)
+            self.comm.all_gather_flat(a.padded("params", self.world), shard)
+        return StepResult(True, self.world, False, True, dt, replica.updates_applied)
+
+    def gather_optimizer_state(self, replica) -> None:
+        """Sharded mode keeps each range of the optimizer slots current only on its owner; before a
+        checkpoint every replica joins one all-gather per slot buffer so the chief holds all of it."""
+        if not (self.reduce_scatter and self.world > 1):
+            return
+        a = replica.arena
+        shard = a.shard_size(self.world)
+        with replica.stream_ctx():
+            for k in a.slots:
+                self.comm.all_gather_flat(a.padded("slot:" + k, self.world), shard)
 
 
-class Backup(Strategy):
-    name = "backup"
+class _LogStrategy(Strategy):
+    uses_update_log = True
     needs_abort_points = True
+
+    def __init__(self, comm: Communicator, board):
+        super().__init__(comm, board)
+        if board is None and comm.world > 1:
+            raise ValueError(f"{self.name} aggregation needs the shared-memory control board")
+
+    def _result(self, res, done: bool, contributors: int, dt: float) -> StepResult:
+        return StepResult(res.applied > 0, contributors, not done, res.accepted, dt, res.version)
+
+
+class Backup(_LogStrategy):
+    name = "backup"
 
     def __init__(self, comm: Communicator, board, replicas_to_aggregate: int):
         super().__init__(comm, board)
-        if board is None and comm.world > 1:
-            raise ValueError("backup-worker aggregation needs the shared-memory control board")
         self.m = min(max(1, replicas_to_aggregate), comm.world)
 
-    def step(self, replica, step: int, lr: float) -> StepResult:
-        b, m = self.board, self.m
+    def step(self, replica, step: int, lr: LrLike) -> StepResult:
         t0 = time.time()
-        if self.world == 1 or m >= self.world:
-            # nothing can be dropped: plain synchronous step
-            replica.forward_backward(on_bucket=self._bucket_reduce(replica))
-            dt = time.time() - t0
-            with replica.stream_ctx():
-                self.comm.wait_all()
-            replica.apply_update(lr, grad_scale=1.0 / self.world)
-            return StepResult(True, self.world, False, True, dt)
-        b.open_step(step)
-        done = replica.forward_backward(should_abort=lambda: b.stop_requested(step))
-        replica.synchronize()
+        if self.world == 1 or self.board is None:
+            return self._plain_step(replica, lr, t0)
+        log = self._get_log(replica)
+        done = log.forward_backward(replica)
         dt = time.time() - t0
         if done:
-            order = b.arrive(step, self.rank, m)
-            included = order < m
+            res = log.contribute(lr, quorum=self.m, abort_at=self.m)
         else:
-            b.arrive_aborted(step, self.rank)
-            included = False
-        if not included:
-            replica.zero_grads()
-        self._allreduce_full(replica)
-        replica.apply_update(lr, grad_scale=1.0 / m)
-        return StepResult(True, m, not done, included, dt)
+            res = log.skip(lr)   # the update closed while this replica was still back-propagating
+        return self._result(res, done, self.m, dt)
 
 
-class Interval(Strategy):
+class Interval(_LogStrategy):
     name = "interval"
-    needs_abort_points = True
+    needs_abort_points = False
 
-    def __init__(self, comm: Communicator, board, interval_ms: float):
+    def __init__(self, comm: Communicator, board, interval_ms: float, max_staleness: int = -1):
         super().__init__(comm, board)
-        if board is None and comm.world > 1:
-            raise ValueError("interval aggregation needs the shared-memory control board")
-        self.interval_ns = int(interval_ms * 1e6)
+        self.interval_s = float(interval_ms) / 1e3
+        self.max_staleness = max_staleness
+        self._timer: Optional[threading.Thread] = None
+        self._timer_stop = threading.Event()
+        self.windows_closed = 0
+        self._lr: LrLike = 0.0
 
-    def step(self, replica, step: int, lr: float) -> StepResult:
-        b = self.board
+    def start_interval_updates(self, replica) -> None:
+        """Chief only: starts the timer that closes a window every `interval_s` whatever the
+        workers are doing (reference: start_interval_updates, sync_replicas_optimizer_modified.py:207-214)."""
+        if self._timer is not None or not self.comm.is_chief:
+            return
+        log = self._get_log(replica)
+
+        def tick() -> None:
+            nxt = time.time() + self.interval_s
+            while not self._timer_stop.wait(max(0.0, nxt - time.time())):
+                nxt += self.interval_s
+                try:
+                    if log.close_window() >= 0:
+                        self.windows_closed += 1
+                except Exception:   # noqa: BLE001 - the training thread reports the failure
+                    self._timer_error = True
+                    return
+
+        self._timer = threading.Thread(target=tick, name="interval-updates", daemon=True)
+        self._timer.start()
+
+    def stop_interval_updates(self) -> None:
+        if self._timer is not None:
+            self._timer_stop.set()
+            self._timer.join(timeout=30)
+            self._timer = None
+
+    def step(self, replica, step: int, lr: LrLike) -> StepResult:
         t0 = time.time()
-        if b is not None:
-            start_ns = b.open_step(step)
-            now = b.now_ns
-        else:
-            start_ns = time.time_ns()
-            now = time.time_ns
-        deadline = start_ns + self.interval_ns
-        done = replica.forward_backward(should_abort=lambda: now() > deadline)
-        replica.synchronize()
+        if self.world == 1 and self.board is None:
+            return self._plain_step(replica, lr, t0)
+        log = self._get_log(replica)
+        self.start_interval_updates(replica)
+        log.catch_up(lr, reduce_own=False)      # start from the newest parameters, like a worker reading the parameter server
+        done = log.forward_backward(replica, abortable=False)
         dt = time.time() - t0
-        in_time = done and now() <= deadline
-        if not in_time:
-            replica.zero_grads()
-        aux = replica.arena.aux
-        with replica.stream_ctx():
-            aux.zero_()
-            aux[0] = 1.0 if in_time else 0.0
-        self._allreduce_full(replica, with_aux=True)
-        replica.synchronize()
-        count = int(round(float(aux[0].item())))
-        if count > 0:
-            replica.apply_update(lr, grad_scale=1.0 / count)
-        return StepResult(count > 0, count, not done, in_time, dt)
+        res = log.contribute_open(lr, self.max_staleness)
+        return self._result(res, done, self.board.agg_open_count(), dt)
+
+    def finish(self) -> None:
+        if self.log is not None:
+            self.log.finish()
+        self.stop_interval_updates()
+        super().finish()
 
 
-class SoftKill(Strategy):
+class SoftKill(_LogStrategy):
     name = "soft_kill"
-    needs_abort_points = True
 
     def __init__(self, comm: Communicator, board, should_stop_worker_num: int):
         super().__init__(comm, board)
-        if board is None and comm.world > 1:
-            raise ValueError("soft-kill aggregation needs the shared-memory control board")
         self.k = should_stop_worker_num
 
-    def step(self, replica, step: int, lr: float) -> StepResult:
-        b = self.board
+    def step(self, replica, step: int, lr: LrLike) -> StepResult:
         t0 = time.time()
-        if b is not None:
-            b.open_step(step)
-            done = replica.forward_backward(should_abort=lambda: b.stop_requested(step))
-        else:
-            done = replica.forward_backward()
-        replica.synchronize()
+        if self.world == 1 or self.board is None:
+            return self._plain_step(replica, lr, t0)
+        log = self._get_log(replica)
+        done = log.forward_backward(replica)
         dt = time.time() - t0
-        if b is not None:
-            if done:
-                b.arrive(step, self.rank, self.k)   # raises the stop flag on the k-th arrival
-            else:
-                b.arrive_aborted(step, self.rank)
-        self._allreduce_full(replica)
-        replica.apply_update(lr, grad_scale=1.0 / self.world)
-        return StepResult(True, self.world, not done, True, dt)
+        # a short-circuited replica still pushes what it has (zeros for the layers it did not reach)
+        res = log.contribute(lr, quorum=self.world, abort_at=self.k, scale=1.0 / self.world)
+        return self._result(res, done, self.world, dt)
 
 
 def ls_gradient_weights(num_workers: int, num_batches: int, killed: List[int]) -> np.ndarray:
@@ -238,8 +280,9 @@ def ls_gradient_weights(num_workers: int, num_batches: int, killed: List[int]) -
     return w
 
 
-class Weighted(Strategy):
+class Weighted(_LogStrategy):
     name = "weighted"
+    needs_abort_points = False
 
     def __init__(self, comm: Communicator, board, num_worker_kill: int, random_seed: int):
         super().__init__(comm, board)
@@ -251,22 +294,23 @@ class Weighted(Strategy):
         killed = list(rng.choice(self.world, size=self.num_kill, replace=False)) if self.num_kill else []
         return ls_gradient_weights(self.world, self.world, killed)
 
-    def step(self, replica, step: int, lr: float) -> StepResult:
-        w = self.weights_for_step(step)
-        wr = float(w[self.rank])
+    def step(self, replica, step: int, lr: LrLike) -> StepResult:
         t0 = time.time()
-        if wr == 0.0:
-            # a killed worker does no work this iteration
-            replica.zero_grads()
-            done = False
-        else:
-            done = replica.forward_backward()
-            replica.scale_grads(wr)
-        dt = time.time() - t0
-        self._allreduce_full(replica)
+        if self.world == 1 or self.board is None:
+            return self._plain_step(replica, lr, t0)
+        log = self._get_log(replica)
+        # the kill draw belongs to the UPDATE (identical on every replica whatever its iteration count)
+        w = self.weights_for_step(log.version)
+        wr = float(w[self.rank])
+        alive = int((w != 0).sum())
         total = float(w.sum())
-        replica.apply_update(lr, grad_scale=1.0 / total if total > 0 else 0.0)
-        return StepResult(total > 0, int((w != 0).sum()), False, wr != 0.0, dt)
+        if wr == 0.0:
+            res = log.skip(lr)                   # a killed worker does no work for this update
+            return self._result(res, True, alive, time.time() - t0)
+        log.forward_backward(replica, abortable=False)
+        dt = time.time() - t0
+        res = log.contribute(lr, weight=wr, quorum=alive, scale=1.0 / total if total > 0 else 0.0)
+        return self._result(res, True, alive, dt)
 
 
 def make_strategy(flags, comm: Communicator, board, replicas_to_aggregate: int) -> Strategy:
@@ -275,7 +319,7 @@ def make_strategy(flags, comm: Communicator, board, replicas_to_aggregate: int) 
     if getattr(flags, "weighted_grads_method", False):
         return Weighted(comm, board, flags.num_worker_kill, flags.random_seed)
     if flags.interval_method:
-        return Interval(comm, board, flags.interval_ms)
+        return Interval(comm, board, flags.interval_ms, getattr(flags, "interval_max_staleness", -1))
     if flags.soft_kill_method:
         return SoftKill(comm, board, flags.should_stop_worker_num)
     if flags.backup_worker_method and replicas_to_aggregate < comm.world:

@@ -16,6 +16,11 @@ from typing import Dict, Iterable, Iterator, List, Sequence, Tuple
 import torch
 
 ALIGN_FLOATS = 64  # 256 bytes: keeps every tensor 16-byte aligned for dwordx4 access
+MAX_SHARD_WORLD = 64
+# Unused tail behind the last tensor of every flat buffer. Sharded modes cut the buffer into `world`
+# EQUAL ranges of ceil(total / (64 * world)) * 64 floats, the last of which reaches into this tail,
+# so a reduce-scatter / all-gather is one collective of uniform chunks whatever the model size.
+SHARD_PAD_FLOATS = ALIGN_FLOATS * MAX_SHARD_WORLD
 
 
 @dataclass(frozen=True)
@@ -48,14 +53,23 @@ class ParamArena:
             self.offsets[s.name] = off
             off += (s.numel + ALIGN_FLOATS - 1) // ALIGN_FLOATS * ALIGN_FLOATS
         self.total = off
-        self.params = torch.zeros(self.total, dtype=torch.float32, device=self.device)
-        # The gradient buffer carries a small tail that the optimizer never touches: strategies
-        # put per-step scalars there (e.g. "my gradient is part of this update") so they travel
-        # in the same collective as the gradients.
-        self.grads_full = torch.zeros(self.total + ALIGN_FLOATS, dtype=torch.float32, device=self.device)
+        self.capacity = self.total + SHARD_PAD_FLOATS
+        # Every flat buffer has the same layout: [0, total) tensors, [total, capacity) zero padding
+        # that only the sharded collectives and the per-shard optimizer ever touch (zeros stay
+        # zeros under Adam and momentum SGD).
+        self._full: Dict[str, torch.Tensor] = {"params": torch.zeros(self.capacity, dtype=torch.float32, device=self.device)}
+        self.params = self._full["params"][: self.total]
+        # The gradient buffer carries a small tail behind the padding that the optimizer never
+        # touches: strategies put per-step scalars there (e.g. "my gradient is part of this
+        # update") so they travel in the same collective as the gradients.
+        self.grads_full = torch.zeros(self.capacity + ALIGN_FLOATS, dtype=torch.float32, device=self.device)
+        self._full["grads"] = self.grads_full[: self.capacity]
         self.grads = self.grads_full[: self.total]
-        self.aux = self.grads_full[self.total:]
-        self.slots: Dict[str, torch.Tensor] = {k: torch.zeros_like(self.params) for k in slots}
+        self.aux = self.grads_full[self.capacity:]
+        self.slots: Dict[str, torch.Tensor] = {}
+        for k in slots:
+            self._full["slot:" + k] = torch.zeros(self.capacity, dtype=torch.float32, device=self.device)
+            self.slots[k] = self._full["slot:" + k][: self.total]
         self._by_name = {s.name: s for s in self.specs}
 
     # -- views -----------------------------------------------------------------------------
@@ -115,17 +129,28 @@ class ParamArena:
             t.zero_()
 
     # -- sharding (reduce-scatter / async parameter shards) -----------------------------------------
+    def shard_size(self, world: int) -> int:
+        if not 1 <= world <= MAX_SHARD_WORLD:
+            raise ValueError(f"sharding supports 1..{MAX_SHARD_WORLD} ranks")
+        quanta = (self.total + ALIGN_FLOATS - 1) // ALIGN_FLOATS
+        return (quanta + world - 1) // world * ALIGN_FLOATS
+
     def shard_bounds(self, world: int) -> List[Tuple[int, int]]:
-        """Splits [0, total) into `world` contiguous ranges whose sizes are multiples of the
-        alignment quantum (the last one takes the remainder)."""
-        quanta = self.total // ALIGN_FLOATS
-        base, rem = divmod(quanta, world)
-        bounds, start = [], 0
-        for r in range(world):
-            n = (base + (1 if r < rem else 0)) * ALIGN_FLOATS
-            bounds.append((start, start + n))
-            start += n
-        return bounds
+        """`world` EQUAL contiguous ranges of `shard_size(world)` floats covering [0, total); the
+        last ranges may reach into the zero padding behind `total` (index the buffers returned
+        by `padded()` with them, not `params` / `grads`)."""
+        n = self.shard_size(world)
+        return [(r * n, (r + 1) * n) for r in range(world)]
+
+    def full(self, which: str) -> torch.Tensor:
+        """A flat buffer with its padding ("params", "grads", "slot:<name>"): shard ranges from
+        `shard_bounds` index this, since the last shards reach behind `total`."""
+        return self._full[which]
+
+    def padded(self, which: str, world: int) -> torch.Tensor:
+        """View of a flat buffer ("params", "grads", "slot:m", ...) over all `world` equal shards,
+        padding included: what the sharded collectives and the per-shard optimizer address."""
+        return self._full[which][: self.shard_size(world) * world]
 
     def state_dict(self, use_tf_names: bool = False) -> Dict[str, torch.Tensor]:
         out = {}

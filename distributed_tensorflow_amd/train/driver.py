@@ -147,7 +147,9 @@ def train(flags, model: str) -> Dict:
     board = None
     if needs_board:
         name = flags.board_name or control_plane.board_name_for(train_dir, task.master_port)
-        board = control_plane.open_board(name, world, rank)
+        board = control_plane.open_board(name, world, rank, control_plane.run_nonce(comm))
+        if is_chief:
+            control_plane.unlink_on_sigterm(name)
 
     # ---- data
     batch_size = flags.batch_size
@@ -217,6 +219,7 @@ def train(flags, model: str) -> Dict:
         strategy = None
     else:
         strategy = make_strategy(flags, comm, board, num_replicas_to_aggregate)
+        strategy.start_version = global_step
         log.info("Worker %d: aggregation policy %s over %d replicas (aggregate %d)", rank, strategy.name, world, num_replicas_to_aggregate)
 
     timeout_client, timeout_server = control_plane.launch_manager(board, rank, world, flags.collective_timeout_s)
@@ -236,6 +239,8 @@ def train(flags, model: str) -> Dict:
         for r in range(world):
             board.put_tokens(r, 1, global_step)   # init tokens (reference: get_init_tokens_op)
     aborted_steps = excluded_steps = 0
+    lr_schedule = lr_mod.StaircaseSchedule(flags.initial_learning_rate, decay_steps, flags.learning_rate_decay_factor)
+    sharded = (not async_mode) and getattr(strategy, "reduce_scatter", False) and world > 1
     window_start, window_steps = time.time(), 0   # since the last training line (log_every > 1)
 
     while not sv.should_stop():
@@ -262,10 +267,11 @@ def train(flags, model: str) -> Dict:
             if board.global_step() > flags.max_steps:
                 board.request_stop()
         else:
-            lr = lr_mod.exponential_decay(flags.initial_learning_rate, global_step, decay_steps, flags.learning_rate_decay_factor)
             with timeline.span("train_step", getattr(replica, "stream", None)):
-                res = strategy.step(replica, cur_iteration, lr)
-            if res.applied:
+                res = strategy.step(replica, cur_iteration, lr_schedule)
+            if res.global_step is not None:
+                global_step = res.global_step     # a replica that catches up applies several updates in one call
+            elif res.applied:
                 global_step += 1
             aborted_steps += int(res.aborted)
             excluded_steps += int(not res.included)
@@ -322,7 +328,16 @@ def train(flags, model: str) -> Dict:
                 summary_writer.add_histograms(histograms, step)
             log.info("Finished running Summary operation.")
             next_summary_time += flags.save_summaries_secs
-        sv.maybe_save(step, replica.updates_applied)
+        if sharded:
+            # each range of the optimizer slots is current only on its owner: every replica joins
+            # the gather at the SAME iteration, which the chief announces two iterations ahead
+            if is_chief and sv.save_due(step) and board.save_step() < cur_iteration:
+                board.request_save(cur_iteration + 2)
+            if board.save_step() == cur_iteration:
+                strategy.gather_optimizer_state(replica)
+                sv.maybe_save(step, replica.updates_applied, force=True)
+        else:
+            sv.maybe_save(step, replica.updates_applied)
         if board is not None:
             board.heartbeat(rank)
 
@@ -330,6 +345,12 @@ def train(flags, model: str) -> Dict:
         shards.drain(flags.collective_timeout_s)
         global_step = board.global_step()
         shards.close()
+    if strategy is not None:
+        strategy.finish()
+        if strategy.uses_update_log:
+            global_step = replica.updates_applied
+        if sharded:
+            strategy.gather_optimizer_state(replica)
     replica.synchronize()
     if is_chief:
         log.info("Elapsed Time: %f" % (time.time() - begin_time))

@@ -137,11 +137,12 @@ class TorchReplica(ReplicaBase):
         """Optimizer over the flat range [lo, hi) only (sharded-optimizer mode: this replica owns
         that range of parameters and optimizer slots)."""
         a = self.arena
-        g = a.grads[lo:hi] * grad_scale if grad_scale != 1.0 else a.grads[lo:hi]
+        p, gr, m = a.full("params")[lo:hi], a.full("grads")[lo:hi], a.full("slot:m")[lo:hi]
+        g = gr * grad_scale if grad_scale != 1.0 else gr
         if self.optimizer == "adam":
-            ref.adam_update(a.params[lo:hi], g, a.slots["m"][lo:hi], a.slots["v"][lo:hi], self.adam_lr_t(lr))
+            ref.adam_update(p, g, m, a.full("slot:v")[lo:hi], self.adam_lr_t(lr))
         else:
-            ref.momentum_update(a.params[lo:hi], g, a.slots["m"][lo:hi], lr, self.momentum, self.weight_decay)
+            ref.momentum_update(p, g, m, lr, self.momentum, self.weight_decay)
         self.updates_applied += 1
 
     def zero_grads(self) -> None:
@@ -258,10 +259,11 @@ class HipReplica(ReplicaBase):
             lr_t = self.adam_lr_t(lr) if self.optimizer == "adam" else lr
             st.set_hyper(lr_t=lr_t, grad_scale=grad_scale, momentum=self.momentum, weight_decay=self.weight_decay)
             if hi > lo:
+                p, g, m = a.full("params")[lo:hi], a.full("grads")[lo:hi], a.full("slot:m")[lo:hi]
                 if self.optimizer == "adam":
-                    nv.fused_adam(a.params[lo:hi], a.grads[lo:hi], a.slots["m"][lo:hi], a.slots["v"][lo:hi], st.hyper)
+                    nv.fused_adam(p, g, m, a.full("slot:v")[lo:hi], st.hyper)
                 else:
-                    nv.fused_momentum_sgd(a.params[lo:hi], a.grads[lo:hi], a.slots["m"][lo:hi], st.hyper)
+                    nv.fused_momentum_sgd(p, g, m, st.hyper)
         self.updates_applied += 1
 
     def zero_grads(self) -> None:

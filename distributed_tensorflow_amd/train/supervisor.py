@@ -56,9 +56,15 @@ class Supervisor:
     def request_stop(self) -> None:
         self._stop.set()
 
-    def maybe_save(self, global_step: int, updates_applied: int) -> bool:
-        """Called between steps on the chief; snapshots and queues a save when one is due."""
-        if not self.is_chief or time.time() < self._next_save or global_step == self.last_saved_step:
+    def save_due(self, global_step: int) -> bool:
+        return self.is_chief and time.time() >= self._next_save and global_step != self.last_saved_step
+
+    def maybe_save(self, global_step: int, updates_applied: int, force: bool = False) -> bool:
+        """Called between steps on the chief; snapshots and queues a save when one is due (or when
+        `force`d: the replicas have just gathered sharded optimizer state for this save)."""
+        if not self.is_chief or global_step == self.last_saved_step:
+            return False
+        if not force and time.time() < self._next_save:
             return False
         self._next_save = time.time() + self.save_interval_secs
         snap = self.saver.snapshot(global_step, updates_applied)

@@ -41,7 +41,9 @@ def _full_sync_worker(rank, world, board_name, sharded=False):
     torch.distributed.all_gather(gathered, own)
     mean = torch.stack(gathered).mean(0)
     p0 = rep.arena.params.clone()
+    issued0 = comm.collectives_issued
     res = FullSync(comm, board, reduce_scatter=sharded).step(rep, 0, 1e-3)
+    issued = comm.collectives_issued - issued0
     # expected: Adam's first step on the mean gradient
     from distributed_tensorflow_amd.ops import reference as ref
 
@@ -50,21 +52,24 @@ def _full_sync_worker(rank, world, board_name, sharded=False):
     err = float((rep.arena.params - want).abs().max())
     comm.barrier()
     comm.close()
-    return res.contributors, err, rep.arena.params.sum().item()
+    return res.contributors, err, rep.arena.params.sum().item(), issued
 
 
 def test_full_sync_is_the_mean_of_all_replicas():
     out = run_workers(_full_sync_worker, 3, f"dtf_t_sync_{os.getpid()}")
-    assert all(c == 3 for c, _, _ in out)
-    assert all(e < 1e-6 for _, e, _ in out)
-    assert len({round(s, 4) for _, _, s in out}) == 1           # identical parameters everywhere
+    assert all(c == 3 for c, _, _, _ in out)
+    assert all(e < 1e-6 for _, e, _, _ in out)
+    assert len({round(s, 4) for _, _, s, _ in out}) == 1        # identical parameters everywhere
+    assert all(n == 1 for _, _, _, n in out)                    # one all-reduce for a gradient this small
 
 
 def test_sharded_optimizer_matches_the_replicated_update():
     # reduce-scatter + per-shard Adam + all-gather must give the same parameters as all-reduce + full Adam
+    # (3 ranks: the arena size is not divisible by the world size, the shards reach into the padding)
     out = run_workers(_full_sync_worker, 3, f"dtf_t_rs_{os.getpid()}", True)
-    assert all(e < 1e-6 for _, e, _ in out)
-    assert len({round(s, 4) for _, _, s in out}) == 1
+    assert all(e < 1e-6 for _, e, _, _ in out)
+    assert len({round(s, 4) for _, _, s, _ in out}) == 1
+    assert all(n == 2 for _, _, _, n in out)                    # ONE reduce-scatter + ONE all-gather per step
 
 
 def _backup_worker(rank, world, board_name, m, slow_rank):
@@ -77,31 +82,69 @@ def _backup_worker(rank, world, board_name, m, slow_rank):
     torch.distributed.all_gather(gathered, own)
     p0 = rep.arena.params.clone()
     strat = Backup(comm, board, m)
+    strat._get_log(rep)                                      # set-up (collective) outside the timed step
     comm.barrier()
     if rank == slow_rank:
-        time.sleep(1.0)                                      # the straggler
+        time.sleep(1.5)                                      # the straggler
     t0 = time.time()
     res = strat.step(rep, 0, 1e-3)
     dt = time.time() - t0
-    mask = board.mask(0)
+    count, mask, owners, scale = board.agg_entry(0)
     fast = [r for r in range(world) if r != slow_rank]
     mean = torch.stack([gathered[r] for r in fast]).mean(0)
     want = p0.clone()
     ref.adam_update(want, mean, torch.zeros_like(want), torch.zeros_like(want), ref.adam_lr_t(1e-3, 1))
     err = float((rep.arena.params - want).abs().max())
-    comm.barrier()
+    strat.finish()
     comm.close()
-    return dict(included=res.included, contributors=res.contributors, err=err, mask=mask, dt=dt, updates=rep.updates_applied)
+    return dict(included=res.included, contributors=res.contributors, err=err, mask=mask, dt=dt, updates=rep.updates_applied,
+                gs=res.global_step)
 
 
-def test_backup_workers_drop_exactly_the_straggler_and_everyone_advances():
+def test_backup_workers_drop_exactly_the_straggler_and_nobody_waits_for_it():
     world, m, slow = 3, 2, 1
     out = run_workers(_backup_worker, world, f"dtf_t_bk_{os.getpid()}", m, slow)
     assert [o["included"] for o in out] == [True, False, True]
     assert all(o["contributors"] == m for o in out)
     assert all(o["mask"] == 0b101 for o in out)               # first M arrivals, agreed by all replicas
     assert all(o["err"] < 1e-6 for o in out)                  # update = mean of the two fresh gradients
-    assert all(o["updates"] == 1 for o in out)                # the straggler moved on too
+    assert all(o["updates"] == 1 and o["gs"] == 1 for o in out)   # the straggler moved on too
+    # the property that matters: the fast replicas' step does not contain the straggler's 1.5 s
+    assert out[0]["dt"] < 0.75 and out[2]["dt"] < 0.75, [o["dt"] for o in out]
+
+
+def _backup_stress_worker(rank, world, board_name, m, steps):
+    import random
+
+    from distributed_tensorflow_amd.parallel.strategies import Backup
+
+    comm, board, rep, images, labels = _setup(rank, world, board_name)
+    strat = Backup(comm, board, m)
+    rng = random.Random(7 + rank)
+    included = 0
+    it = 0
+    while True:
+        g = torch.Generator().manual_seed(1000 * it + rank)
+        rep.load_batch(torch.randn(BATCH, 32, 32, 3, generator=g), torch.randint(0, 10, (BATCH,), generator=g))
+        if rng.random() < 0.3:
+            time.sleep(rng.random() * 0.03)                    # uneven load: random per-step delays
+        res = strat.step(rep, it, 1e-3)
+        included += int(res.included)
+        it += 1
+        if res.global_step >= steps:
+            break
+    strat.finish()
+    psum = rep.arena.params.double().sum().item()
+    comm.close()
+    return dict(psum=psum, version=rep.updates_applied, included=included, iters=it)
+
+
+def test_backup_stress_uneven_load_keeps_replicas_identical():
+    world, m, steps = 3, 2, 60
+    out = run_workers(_backup_stress_worker, world, f"dtf_t_bks_{os.getpid()}", m, steps, timeout=600)
+    assert len({o["version"] for o in out}) == 1 and out[0]["version"] >= steps
+    assert len({round(o["psum"], 6) for o in out}) == 1       # same updates in the same order everywhere
+    assert sum(o["included"] for o in out) == m * out[0]["version"]   # every update took exactly M gradients
 
 
 def _soft_kill_worker(rank, world, board_name, k, slow_rank):
@@ -109,15 +152,15 @@ def _soft_kill_worker(rank, world, board_name, k, slow_rank):
 
     comm, board, rep, images, labels = _setup(rank, world, board_name)
     strat = SoftKill(comm, board, k)
+    strat._get_log(rep)
     comm.barrier()
     if rank == slow_rank:
         # arrive after the others are done, so the stop flag is already up when backprop starts
         deadline = time.time() + 30
-        while board.arrivals(0) < k and time.time() < deadline:
+        while board.agg_open_count() < k and time.time() < deadline:
             time.sleep(0.01)
     res = strat.step(rep, 0, 1e-3)
-    nz = int((rep.arena.grads != 0).sum())
-    comm.barrier()
+    strat.finish()
     comm.close()
     return dict(aborted=res.aborted, contributors=res.contributors, psum=rep.arena.params.sum().item())
 
@@ -130,31 +173,58 @@ def test_soft_kill_short_circuits_the_straggler():
     assert len({round(o["psum"], 4) for o in out}) == 1
 
 
-def _interval_worker(rank, world, board_name, interval_ms, slow_rank):
+def _interval_worker(rank, world, board_name, interval_ms, slow_rank, run_s):
     from distributed_tensorflow_amd.parallel.strategies import Interval
 
     comm, board, rep, images, labels = _setup(rank, world, board_name)
     strat = Interval(comm, board, interval_ms)
+    strat._get_log(rep)
     comm.barrier()
-    res0 = strat.step(rep, 0, 1e-3)                            # everyone in time
+    t_end = time.time() + run_s
+    pushes = accepted = 0
+    longest = 0.0
+    it = 0
+    while time.time() < t_end:
+        if rank == slow_rank:
+            time.sleep(3 * interval_ms / 1e3)                  # three windows per gradient
+        else:
+            time.sleep(0.6 * interval_ms / 1e3)
+        t0 = time.time()
+        res = strat.step(rep, it, 1e-3)
+        longest = max(longest, time.time() - t0)
+        pushes += 1
+        accepted += int(res.included)
+        it += 1
     comm.barrier()
-    board.open_step(1)                                         # the window opens now for all
-    if rank == slow_rank:
-        time.sleep(interval_ms / 1e3 + 0.3)                    # misses the deadline
-    res1 = strat.step(rep, 1, 1e-3)
-    comm.barrier()
+    strat.log.catch_up(1e-3, reduce_own=False)
+    closed = strat.windows_closed
+    version = strat.log.version
+    hist = []
+    for u in range(max(0, version - 8), version):
+        count, mask, owners, scale = board.agg_entry(u)
+        hist.append((count, mask))
+    strat.finish()
     comm.close()
-    return dict(c0=res0.contributors, c1=res1.contributors, inc1=res1.included, applied=(res0.applied, res1.applied),
-                psum=rep.arena.params.sum().item())
+    return dict(pushes=pushes, accepted=accepted, version=version, closed=closed, psum=rep.arena.params.double().sum().item(),
+                longest=longest, hist=hist)
 
 
-def test_interval_aggregates_what_arrived_in_time():
-    world, slow = 3, 0
-    out = run_workers(_interval_worker, world, f"dtf_t_iv_{os.getpid()}", 1500, slow)
-    assert all(o["c0"] == world for o in out)
-    assert all(o["c1"] == world - 1 for o in out)
-    assert [o["inc1"] for o in out] == [False, True, True]
-    assert len({round(o["psum"], 4) for o in out}) == 1
+def test_interval_timer_closes_windows_while_workers_never_wait():
+    world, slow, interval_ms, run_s = 3, 2, 120, 3.0
+    out = run_workers(_interval_worker, world, f"dtf_t_iv_{os.getpid()}", interval_ms, slow, run_s)
+    version = out[0]["version"]
+    assert len({o["version"] for o in out}) == 1
+    assert len({round(o["psum"], 6) for o in out}) == 1
+    # global_step advances at the timer's rate, not at the slow replica's
+    assert 0.6 * run_s * 1e3 / interval_ms <= version <= 1.3 * run_s * 1e3 / interval_ms, version
+    assert out[0]["closed"] == version
+    # the slow replica pushes about every third window and every push is accepted (never stale here)
+    assert out[slow]["accepted"] == out[slow]["pushes"]
+    assert 0.2 * version <= out[slow]["pushes"] <= 0.5 * version, (out[slow]["pushes"], version)
+    with_slow = sum(1 for c, m in out[0]["hist"] if (m >> slow) & 1)
+    assert 1 <= with_slow <= 5
+    # pushing never blocks on the timer or on another replica (a step here is compute + push)
+    assert all(o["longest"] < 3 * interval_ms / 1e3 + 1.0 for o in out)
 
 
 def _weighted_worker(rank, world, board_name):
@@ -164,7 +234,7 @@ def _weighted_worker(rank, world, board_name):
     strat = Weighted(comm, board, num_worker_kill=1, random_seed=142)
     w = strat.weights_for_step(0)
     res = strat.step(rep, 0, 1e-3)
-    comm.barrier()
+    strat.finish()
     comm.close()
     return dict(w=w.tolist(), included=res.included, psum=rep.arena.params.sum().item())
 
@@ -234,3 +304,44 @@ def test_async_staleness_bound_drops_old_gradients():
     assert applied + dropped == world * world * steps
     assert dropped > 0            # tau = 0: a gradient computed before another update landed is discarded
     assert len({round(o["psum"], 3) for o in out}) == 1
+
+
+def _sharded_ckpt_worker(rank, world, board_name, tmp):
+    from distributed_tensorflow_amd.checkpoint.saver import Saver
+    from distributed_tensorflow_amd.parallel.strategies import FullSync
+
+    comm, board, rep, images, labels = _setup(rank, world, board_name)
+    strat = FullSync(comm, board, reduce_scatter=True)
+    for i in range(3):
+        strat.step(rep, i, 1e-3)
+    # without the gather the chief's slots are current only inside its own shard
+    shard = rep.arena.shard_size(world)
+    stale_outside = float(rep.arena.slots["m"][shard:].abs().max()) if rank == 0 else 0.0
+    strat.gather_optimizer_state(rep)
+    saver = Saver(rep.arena, "adam")
+    prefix = None
+    if rank == 0:
+        prefix = saver.save(tmp, 3, rep.updates_applied)
+    prefix = comm.all_gather_object(prefix)[0]
+    strat.step(rep, 3, 1e-3)                                   # the uninterrupted run's 4th step
+    want = rep.arena.params.clone()
+    # resume: fresh replica restored from the checkpoint, same 4th step
+    from distributed_tensorflow_amd.train.replica import TorchReplica
+
+    rep2 = TorchReplica("resnet", BATCH, num_residual_blocks=1, optimizer="adam")
+    rep2.load_batch(images, labels)
+    step = Saver(rep2.arena, "adam").restore(prefix)
+    rep2.updates_applied = step
+    FullSync(comm, board, reduce_scatter=True).step(rep2, 3, 1e-3)
+    err = float((rep2.arena.params - want).abs().max())
+    m_nonzero = float(rep2.arena.slots["m"].abs().sum())
+    comm.barrier()
+    comm.close()
+    return dict(err=err, stale_outside=stale_outside, m_nonzero=m_nonzero, step=step)
+
+
+def test_sharded_optimizer_checkpoint_holds_every_shards_slots(tmp_path):
+    out = run_workers(_sharded_ckpt_worker, 3, f"dtf_t_rsck_{os.getpid()}", str(tmp_path))
+    assert out[0]["stale_outside"] == 0.0                      # (the defect the gather exists for)
+    assert all(o["step"] == 3 and o["m_nonzero"] > 0 for o in out)
+    assert all(o["err"] < 1e-7 for o in out)                   # resumed run == uninterrupted run
