@@ -9,6 +9,7 @@
 #include <pybind11/stl.h>
 
 #include "comm/p2p_allreduce.h"
+#include "comm/update_log.h"
 #include "kernels/conv.h"
 #include "kernels/ops.h"
 #include "runtime/program.h"
@@ -275,6 +276,49 @@ PYBIND11_MODULE(_hip, m) {
     p2p_allreduce(a, blocks, as_stream(stream));
   });
   m.attr("P2P_FLAG_BLOCK_BYTES") = (uint64_t)kFlagBlockBytes;
+  // ---------------------------------------------------------------- update log (non-blocking aggregation)
+  {
+    auto fill = [](const py::dict& d) {
+      UlogArgs a{};
+      auto ctl = d["ctl"].cast<std::vector<uint64_t>>();
+      auto stage = d["stage"].cast<std::vector<uint64_t>>();
+      auto red = d["red"].cast<std::vector<uint64_t>>();
+      V(rank); V(world); V(n);
+      if ((int)ctl.size() != a.world || (int)stage.size() != a.world || (int)red.size() != a.world || a.world > kUlogMaxPeers)
+        throw std::runtime_error("update log: per-rank lists must have `world` (at most 8) entries");
+      for (int p = 0; p < a.world; ++p) {
+        a.ctl[p] = reinterpret_cast<unsigned long long*>(ctl[p]);
+        a.stage[p] = reinterpret_cast<float*>(stage[p]);
+        a.red[p] = reinterpret_cast<float*>(red[p]);
+      }
+      P(grads, const float); P(p, float); P(m, float); P(v, float); P(status, unsigned long long);
+      V(mode); V(quorum); V(abort_at); V(scale); V(weight); V(max_version); V(max_staleness); V(opt);
+      V(lr0); V(decay); V(decay_steps); V(beta1); V(beta2); V(eps); V(momentum); V(weight_decay); V(timeout_ticks);
+      return a;
+    };
+    m.def("ulog_step", [fill](const py::dict& d, int blocks, uint64_t stream) { ulog_step(fill(d), blocks, as_stream(stream)); });
+    m.def("ulog_close", [fill](const py::dict& d, int blocks, uint64_t stream) { ulog_close(fill(d), blocks, as_stream(stream)); });
+    m.def("ulog_init_ctl", [](uint64_t ctl, long long u0, uint64_t stream) {
+      ulog_init_ctl(reinterpret_cast<unsigned long long*>(ctl), u0, as_stream(stream));
+    });
+    m.def("ulog_mark_dead", [](uint64_t ctl, unsigned mask, uint64_t stream) {
+      ulog_mark_dead(reinterpret_cast<unsigned long long*>(ctl), mask, as_stream(stream));
+    });
+    m.def("ulog_peek", [](uint64_t ctl, int first, int count) {
+      std::vector<unsigned long long> out(count > 0 ? count : 0);
+      ulog_peek(reinterpret_cast<const unsigned long long*>(ctl), first, count, out.data());
+      return out;
+    });
+    m.def("ulog_poke", [](uint64_t ctl, int word, unsigned long long value) {
+      ulog_poke(reinterpret_cast<unsigned long long*>(ctl), word, value);
+    });
+    m.attr("ULOG_CTL_BYTES") = (uint64_t)kUlogCtlBytes;
+    m.attr("ULOG_RING") = (int)kUlogRing;
+    m.attr("ULOG_WORD_BYTES") = (int)(kUlogWordStride * sizeof(unsigned long long));
+    m.attr("UW_OPEN") = (int)UW_OPEN; m.attr("UW_ABORT") = (int)UW_ABORT; m.attr("UW_VERSION") = (int)UW_VERSION;
+    m.attr("UW_ERROR") = (int)UW_ERROR; m.attr("UW_APPLIED") = (int)UW_APPLIED; m.attr("UW_STATS") = (int)UW_STATS;
+    m.attr("UW_HIST_TAG") = (int)UW_HIST_TAG; m.attr("UW_HIST_AUX") = (int)UW_HIST_AUX;
+  }
   m.def("ipc_alloc", [](uint64_t bytes, bool fine) { return (uint64_t)ipc_alloc(bytes, fine); });
   m.def("ipc_free", [](uint64_t p) { ipc_free(reinterpret_cast<void*>(p)); });
   m.def("ipc_export", [](uint64_t p) { return py::bytes(ipc_export(reinterpret_cast<void*>(p))); });
@@ -355,6 +399,14 @@ PYBIND11_MODULE(_hip, m) {
     P(src, const float); P(index, const int); P(offs, const int); P(out, float);
     V(B); V(HP); V(WP); V(H); V(W); V(C); V(whiten);
     crop_whiten(a, as_stream(stream));
+  });
+
+  // Short-circuit reference handed to every training kernel launched or recorded afterwards from
+  // this thread (0, 0 disables it).
+  m.def("set_abort_ref", [](uint64_t stop, uint64_t version) {
+    if ((stop == 0) != (version == 0)) throw std::runtime_error("set_abort_ref: both words or neither");
+    current_abort_ref().stop = reinterpret_cast<const unsigned long long*>(stop);
+    current_abort_ref().version = reinterpret_cast<const unsigned long long*>(version);
   });
 
   // ---------------------------------------------------------------- step programs

@@ -1,0 +1,577 @@
+// See update_log.h for the protocol. Structure of one ulog_step launch (G blocks):
+//
+//   stage            all blocks copy (or add) the gradient into the own staging buffer
+//   leader step 1    block 0, thread 0: arrival compare-exchange on the coordinator's word, closes the
+//                    update if it completed the quorum, decides what happens next
+//   while APPLY:     (update u = this replica's version)
+//     reduce         an owner sums its shard over the contributors' staging buffers
+//     leader step    publish the shard, wait for all owners' shards
+//     gather         every block reads the owners' shards and applies the optimizer to its slice
+//     leader step    version = u + 1, pushed to every peer; decide what happens next
+//
+// A "leader step" is a grid rendezvous with a verdict: every block reports in on a counter, block 0
+// waits for all of them, runs the single-thread protocol action and publishes a tagged verdict that
+// the other blocks wait for; verdicts are what keeps the blocks' control flow identical. All blocks
+// of the launch must be co-resident (at most kUlogMaxBlocks of 256 threads).
+#include "update_log.h"
+
+#include <stdexcept>
+
+#include "../kernels/optim_math.h"
+
+namespace dtf {
+namespace {
+
+using u64 = unsigned long long;
+
+constexpr u64 kFrozen = 1ull << 31;
+constexpr u64 kActDone = 0, kActApply = 1, kActError = 2, kActOk = 3;
+
+enum UlogError : int {
+  UE_BACKPRESSURE = 1,   // the slowest live replica did not catch up in time
+  UE_GRID = 2,           // the blocks of a launch did not all report in (not co-resident?)
+  UE_RECYCLED = 3,       // this replica fell more than kUlogRing updates behind
+  UE_CLOSE = 4,          // the update this replica contributed to never closed
+  UE_READY = 5,          // an owner never published its reduced shard
+  UE_FROZEN = 6,         // a window stayed frozen (its closer never opened the next one)
+};
+
+__device__ __forceinline__ u64* W(u64* ctl, int word) { return ctl + (size_t)word * kUlogWordStride; }
+__device__ __forceinline__ u64 ld(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ u64 ld_acq(const u64* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_rel(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ bool cas(u64* p, u64& expected, u64 desired) {
+  return __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void acquire_fence() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
+__device__ __forceinline__ void nap() { __builtin_amdgcn_s_sleep(8); }
+
+__device__ __forceinline__ long long open_u(u64 w) { return (long long)(w >> 32); }
+__device__ __forceinline__ int open_count(u64 w) { return (int)((w >> 16) & 0x7fff); }
+__device__ __forceinline__ unsigned open_mask(u64 w) { return (unsigned)(w & 0xffff); }
+__device__ __forceinline__ u64 make_open(long long u, int count, unsigned mask, bool frozen) {
+  return ((u64)u << 32) | (frozen ? kFrozen : 0ull) | ((u64)(count & 0x7fff) << 16) | (u64)(mask & 0xffff);
+}
+
+struct Rec {
+  int count;
+  unsigned mask, owners;
+  float scale;
+  bool closer_reduces;
+};
+
+// 1: update u is closed (record in r); 0: not closed yet; -1: the slot already serves a later update
+__device__ __forceinline__ int read_hist(u64* own, long long u, Rec& r) {
+  const int slot = (int)(u % kUlogRing);
+  const u64 t = ld_acq(W(own, UW_HIST_TAG + slot));
+  const long long tu = (long long)(t >> 32) - 1;
+  if (tu > u) return -1;
+  if (tu != u) return 0;
+  const u64 aux = ld(W(own, UW_HIST_AUX + slot));
+  if (ld_acq(W(own, UW_HIST_TAG + slot)) != t) return -1;
+  r.count = (int)((t >> 16) & 0xffff);
+  r.mask = (unsigned)(t & 0xffff);
+  r.owners = (unsigned)((aux >> 32) & 0xffff);
+  r.scale = __uint_as_float((unsigned)(aux & 0xffffffffull));
+  r.closer_reduces = (aux >> 63) != 0;
+  return 1;
+}
+
+__device__ __forceinline__ bool all_ready(u64* own, long long u, unsigned owners) {
+  const int slot = (int)(u % kUlogRing);
+  for (int p = 0; p < kUlogMaxPeers; ++p)
+    if (((owners >> p) & 1u) && ld(W(own, UW_READY + slot * kUlogMaxPeers + p)) < (u64)(u + 1)) return false;
+  acquire_fence();
+  return true;
+}
+
+__device__ __forceinline__ long long min_applied(const UlogArgs& a) {
+  u64* own = a.ctl[a.rank];
+  const unsigned dead = (unsigned)ld(W(own, UW_DEAD));
+  long long m = 0x7fffffffffffffffll;
+  for (int p = 0; p < a.world; ++p)
+    if (!((dead >> p) & 1u)) {
+      const long long v = (long long)ld(W(own, UW_APPLIED + p));
+      m = v < m ? v : m;
+    }
+  return m;
+}
+
+__device__ __forceinline__ void raise_error(u64* own, int code) {
+  if (ld(W(own, UW_ERROR)) == 0) st(W(own, UW_ERROR), (u64)code);
+}
+
+// Publishes the record of update u on every replica's block and opens u + 1. Called by exactly one
+// thread in the whole job: the one whose compare-exchange set the frozen bit.
+__device__ void publish_closed(const UlogArgs& a, long long u, int count, unsigned mask, unsigned owners, float scale,
+                               bool closer_reduces) {
+  const int slot = (int)(u % kUlogRing);
+  const u64 aux = ((u64)(closer_reduces ? 1 : 0) << 63) | ((u64)(owners & 0xffff) << 32) | (u64)__float_as_uint(scale);
+  const u64 tag = ((u64)(u + 1) << 32) | ((u64)(count & 0xffff) << 16) | (u64)(mask & 0xffff);
+  for (int p = 0; p < a.world; ++p) st(W(a.ctl[p], UW_HIST_AUX + slot), aux);
+  for (int p = 0; p < a.world; ++p) st_rel(W(a.ctl[p], UW_HIST_TAG + slot), tag);
+  st_rel(W(a.ctl[0], UW_OPEN), make_open(u + 1, 0, 0, false));
+}
+
+__device__ void raise_abort_everywhere(const UlogArgs& a, long long value) {
+  for (int p = 0; p < a.world; ++p)
+    __hip_atomic_fetch_max(W(a.ctl[p], UW_ABORT), (u64)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Registers `add` gradients of this replica for update e (any_update: for whatever update is open).
+// 0 accepted, 1 stale (another update is open), 2 late (quorum already complete), 3 timed out.
+__device__ int arrive(const UlogArgs& a, long long e, int add, int quorum, bool any_update, int& order, bool& closed,
+                      long long& open_now) {
+  u64* openw = W(a.ctl[0], UW_OPEN);
+  u64 w = ld_acq(openw);
+  const long long t0 = wall_clock64();
+  order = 0;
+  closed = false;
+  for (;;) {
+    const long long u = open_u(w);
+    open_now = u;
+    if (!any_update && u != e) return 1;
+    if (w & kFrozen) {
+      if (!any_update) return 2;
+      if (wall_clock64() - t0 > a.timeout_ticks) return 3;
+      nap();   // interval mode: the closer opens the next window in a moment
+      w = ld_acq(openw);
+      continue;
+    }
+    const int c = open_count(w), c2 = c + add;
+    const unsigned m2 = open_mask(w) | (1u << a.rank);
+    const bool closes = quorum > 0 && c2 >= quorum;
+    if (cas(openw, w, make_open(u, c2, m2, closes))) {
+      order = c;
+      if (a.abort_at > 0 && c2 >= a.abort_at) raise_abort_everywhere(a, u + 1);
+      if (closes) {
+        closed = true;
+        publish_closed(a, u, c2, m2, m2, a.scale > 0.f ? a.scale : 1.f / (float)c2, false);
+        open_now = u + 1;
+      }
+      return 0;
+    }
+  }
+}
+
+// Interval mode: withdraws this replica's `count` staged gradients from the still-open update e.
+__device__ bool take_back(const UlogArgs& a, long long e, int count) {
+  u64* openw = W(a.ctl[0], UW_OPEN);
+  u64 w = ld_acq(openw);
+  for (;;) {
+    if (open_u(w) != e || (w & kFrozen) || !(open_mask(w) & (1u << a.rank)) || open_count(w) < count) return false;
+    if (cas(openw, w, make_open(e, open_count(w) - count, open_mask(w) & ~(1u << a.rank), false))) return true;
+  }
+}
+
+__device__ __forceinline__ void bump_stat(u64* own, int which, u64 by) { st(W(own, UW_STATS + which), ld(W(own, UW_STATS + which)) + by); }
+
+// ---------------------------------------------------------------------------------------------------
+// ulog_begin: one thread. D0 = seq<<32 | count<<8 | dropped<<2 | stage op (0 none, 1 copy, 2 add).
+__global__ void ulog_begin_kernel(UlogArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  u64* own = a.ctl[a.rank];
+  const u64 seq = ld(W(own, UW_SEQ)) + 1;
+  st(W(own, UW_SEQ), seq);
+  st(W(own, UW_COUNTER), 0);
+  const long long e = (long long)ld(W(own, UW_VERSION));
+  u64 op = 0, count = 1, dropped = 0;
+  if (ld(W(own, UW_ERROR)) == 0) {
+    const long long t0 = wall_clock64();
+    if (a.mode == ULOG_CONTRIBUTE) {
+      if (e < a.max_version) {
+        // the ring slot of update e last served e - ring: every live replica must be past that
+        op = 1;
+        while (min_applied(a) < e - kUlogRing + 1) {
+          if (wall_clock64() - t0 > a.timeout_ticks) {
+            raise_error(own, UE_BACKPRESSURE);
+            op = 0;
+            break;
+          }
+          nap();
+        }
+      }
+    } else if (a.mode == ULOG_OPEN) {
+      op = 1;
+      const u64 pend = ld(W(own, UW_PENDING));
+      bool keep_pending = false;
+      if (pend) {
+        const long long pu = (long long)(pend >> 16) - 1;
+        const int pc = (int)(pend & 0xffff);
+        if (take_back(a, pu, pc)) {
+          op = 2;   // window still open and the staged sum withdrawn: nobody reads it, add to it
+          count = (u64)(pc + 1);
+        } else {
+          // the window closed with the staged sum in it: its owner may still be reading. Nobody waits
+          // in this mode: a gradient that cannot be staged yet is dropped.
+          Rec r;
+          const int c = read_hist(own, pu, r);
+          if (c == 0 || (c == 1 && !all_ready(own, pu, r.owners))) {
+            op = 0;
+            dropped = 1;
+            keep_pending = true;
+          }
+        }
+      }
+      if (op != 0) {
+        const long long open_now = open_u(ld_acq(W(a.ctl[0], UW_OPEN)));
+        if ((a.max_staleness >= 0 && open_now - e > a.max_staleness) || open_now >= a.max_version ||
+            min_applied(a) < open_now - kUlogRing + 1) {
+          op = 0;
+          dropped = open_now < a.max_version ? 1 : 0;
+        }
+      }
+      if (!keep_pending) st(W(own, UW_PENDING), 0);
+    }
+  }
+  st(W(own, UW_D0), (seq << 32) | (count << 8) | (dropped << 2) | op);
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename F>
+__device__ __forceinline__ u64 leader_step(const UlogArgs& a, u64* own, u64 seq, int& nsync, u64* s_payload, F&& fn) {
+  __threadfence_system();   // this block's data is visible before anything the leader publishes
+  __syncthreads();
+  ++nsync;
+  if (threadIdx.x == 0) {
+    const u64 tag = (seq << 16) | (u64)nsync;
+    u64* cnt = W(own, UW_COUNTER);
+    __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();
+    u64 payload = kActError;
+    if (blockIdx.x == 0) {
+      const u64 want = (u64)nsync * gridDim.x;
+      bool ok = true;
+      while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        if (wall_clock64() - t0 > a.timeout_ticks) {
+          ok = false;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (ok)
+        payload = fn();
+      else
+        raise_error(own, UE_GRID);
+      st(W(own, UW_DEC_VAL + (nsync & 3)), payload);
+      __hip_atomic_store(W(own, UW_DEC_TAG + (nsync & 3)), tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      u64* tg = W(own, UW_DEC_TAG + (nsync & 3));
+      bool ok = true;
+      // the leader's own waits may take several timeouts before it gives up
+      while (__hip_atomic_load(tg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+        if (wall_clock64() - t0 > 4 * a.timeout_ticks) {
+          ok = false;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (ok) payload = ld(W(own, UW_DEC_VAL + (nsync & 3)));
+    }
+    *s_payload = payload;
+  }
+  __syncthreads();
+  return *s_payload;
+}
+
+// Leader only: what to do about update u. wait_u: the update this launch must see closed.
+__device__ u64 next_action(const UlogArgs& a, u64* own, long long u, long long wait_u) {
+  if (ld(W(own, UW_ERROR)) != 0) return kActError;
+  const bool patient = a.mode == ULOG_CONTRIBUTE || a.mode == ULOG_SKIP;
+  const long long t0 = wall_clock64();
+  for (;;) {
+    Rec r;
+    const int c = read_hist(own, u, r);
+    if (c == 1) {
+      // a replica that waits for nobody applies only what is already reduced
+      if (!patient && !all_ready(own, u, r.owners)) return kActDone;
+      return kActApply;
+    }
+    if (c < 0) {
+      raise_error(own, UE_RECYCLED);
+      return kActError;
+    }
+    if (u != wait_u) return kActDone;
+    if (wall_clock64() - t0 > a.timeout_ticks) {
+      raise_error(own, UE_CLOSE);
+      return kActError;
+    }
+    nap();
+  }
+}
+
+__global__ __launch_bounds__(256) void ulog_step_kernel(UlogArgs a) {
+  __shared__ u64 s_payload;
+  u64* own = a.ctl[a.rank];
+  const u64 seq = ld(W(own, UW_SEQ));
+  const u64 d0 = ld(W(own, UW_D0));
+  const int op = (int)(d0 & 3);
+  const int add = (int)((d0 >> 8) & 0xffff);
+  const long long n4 = a.n >> 2;
+  const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long gstride = (long long)gridDim.x * blockDim.x;
+  long long version = (long long)ld(W(own, UW_VERSION));
+  int nsync = 0;
+
+  // ---- stage ------------------------------------------------------------------------------------------
+  if (op != 0) {
+    const floatx4* g4 = reinterpret_cast<const floatx4*>(a.grads);
+    floatx4* s4 = reinterpret_cast<floatx4*>(a.stage[a.rank]);
+    if (op == 1)
+      for (long long i = gtid; i < n4; i += gstride) s4[i] = g4[i] * a.weight;
+    else
+      for (long long i = gtid; i < n4; i += gstride) s4[i] += g4[i] * a.weight;
+  }
+
+  // ---- arrive -----------------------------------------------------------------------------------------
+  // leader-only state (block 0, thread 0)
+  long long wait_u = -1;
+  u64 last_flags = 0, applied_now = 0, contributors = 0;
+  u64 act = leader_step(a, own, seq, nsync, &s_payload, [&]() -> u64 {
+    if (op != 0) {
+      int order = 0;
+      bool closed = false;
+      long long open_now = 0;
+      const bool any = a.mode == ULOG_OPEN;
+      const int status = arrive(a, version, add, any ? 0 : a.quorum, any, order, closed, open_now);
+      if (status == 3) {
+        raise_error(own, UE_FROZEN);
+        return kActError;
+      }
+      if (status == 0) {
+        bump_stat(own, US_ACCEPTED, (u64)add);
+        last_flags = 1ull | (closed ? 2ull : 0ull) | ((u64)order << 8);
+        if (any)
+          st(W(own, UW_PENDING), ((u64)(open_now + 1) << 16) | (u64)add);
+        else
+          wait_u = version;
+      } else {
+        bump_stat(own, US_DROPPED, (u64)add);
+        if (status == 2) wait_u = version;   // the closer is publishing this very update: a short wait
+      }
+    } else {
+      if (d0 & 4) bump_stat(own, US_DROPPED, 1);
+      if (a.mode == ULOG_SKIP) wait_u = version;
+    }
+    return next_action(a, own, version, wait_u);
+  });
+
+  // ---- apply every closed update, oldest first --------------------------------------------------------
+  while (act == kActApply) {
+    Rec r;
+    read_hist(own, version, r);   // stable: the slot is not recycled before this replica has applied it
+    const int slot = (int)(version % kUlogRing);
+    const int nown = __popc(r.owners);
+    const long long quanta = (a.n + 63) / 64;
+    const long long chunk4 = (quanta + nown - 1) / nown * 16;   // float4s per owner
+    const bool owner = !r.closer_reduces && ((r.owners >> a.rank) & 1u);
+    if (owner) {
+      const int idx = __popc(r.owners & ((1u << a.rank) - 1u));
+      const long long lo = idx * chunk4;
+      const long long hi = lo + chunk4 < n4 ? lo + chunk4 : n4;
+      floatx4* out = reinterpret_cast<floatx4*>(a.red[a.rank]) + (long long)slot * n4;
+      for (long long i = lo + gtid; i < hi; i += gstride) {
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < a.world; ++q)
+          if ((r.mask >> q) & 1u) acc += __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(a.stage[q]) + i);
+        out[i] = acc;
+      }
+    }
+    u64 ok = leader_step(a, own, seq, nsync, &s_payload, [&]() -> u64 {
+      if (owner)
+        for (int p = 0; p < a.world; ++p) st_rel(W(a.ctl[p], UW_READY + slot * kUlogMaxPeers + a.rank), (u64)(version + 1));
+      const long long t0 = wall_clock64();
+      while (!all_ready(own, version, r.owners)) {
+        if (wall_clock64() - t0 > a.timeout_ticks) {
+          raise_error(own, UE_READY);
+          return kActError;
+        }
+        nap();
+      }
+      return kActOk;
+    });
+    if (ok != kActOk) {
+      act = kActError;
+      break;
+    }
+    acquire_fence();
+
+    // gather the owners' shards, optimizer fused
+    int owner_rank[kUlogMaxPeers];
+    {
+      int k = 0;
+      for (int p = 0; p < kUlogMaxPeers; ++p)
+        if ((r.owners >> p) & 1u) owner_rank[k++] = p;
+      for (; k < kUlogMaxPeers; ++k) owner_rank[k] = a.rank;
+    }
+    const long long t = version + 1;
+    const double lr = (double)a.lr0 * pow((double)a.decay, (double)(version / (a.decay_steps > 0 ? a.decay_steps : 1)));
+    floatx4* p4 = reinterpret_cast<floatx4*>(a.p);
+    floatx4* m4 = reinterpret_cast<floatx4*>(a.m);
+    if (a.opt == ULOG_ADAM) {
+      const float lr_t = (float)(lr * sqrt(1.0 - pow((double)a.beta2, (double)t)) / (1.0 - pow((double)a.beta1, (double)t)));
+      floatx4* v4 = reinterpret_cast<floatx4*>(a.v);
+      for (long long i = gtid; i < n4; i += gstride) {
+        const int k = (int)(i / chunk4);
+        const floatx4 g = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(a.red[owner_rank[k]]) + (long long)slot * n4 + i);
+        floatx4 p = p4[i], m = m4[i], v = v4[i];
+        adam_update4(p, m, v, g, r.scale, lr_t, a.beta1, a.beta2, a.eps);
+        p4[i] = p;
+        m4[i] = m;
+        v4[i] = v;
+      }
+    } else {
+      for (long long i = gtid; i < n4; i += gstride) {
+        const int k = (int)(i / chunk4);
+        const floatx4 g = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(a.red[owner_rank[k]]) + (long long)slot * n4 + i);
+        floatx4 p = p4[i], m = m4[i];
+        momentum_update4(p, m, g, r.scale, (float)lr, a.momentum, a.weight_decay);
+        p4[i] = p;
+        m4[i] = m;
+      }
+    }
+    act = leader_step(a, own, seq, nsync, &s_payload, [&]() -> u64 {
+      st(W(own, UW_VERSION), (u64)(version + 1));
+      for (int p = 0; p < a.world; ++p) st_rel(W(a.ctl[p], UW_APPLIED + a.rank), (u64)(version + 1));
+      ++applied_now;
+      contributors = (u64)r.count;
+      return next_action(a, own, version + 1, wait_u);
+    });
+    ++version;
+  }
+
+  // ---- bookkeeping (leader) ---------------------------------------------------------------------------
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st(W(own, UW_STATS + US_VERSION), ld(W(own, UW_VERSION)));
+    st(W(own, UW_STATS + US_APPLIED), applied_now);
+    st(W(own, UW_STATS + US_LAST), last_flags);
+    st(W(own, UW_STATS + US_ERROR), ld(W(own, UW_ERROR)));
+    if (applied_now) st(W(own, UW_STATS + US_CONTRIB), contributors);
+    st(W(own, UW_STATS + US_SEQ), seq);
+    if (a.status) {
+      for (int k = 1; k < 8; ++k) st(a.status + k, ld(W(own, UW_STATS + k)));
+      st_rel(a.status + US_SEQ, seq);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Chief's interval timer. status (host-visible, nullable): [0] = closed update + 1, or 0.
+__global__ void ulog_close_begin_kernel(UlogArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  u64* own = a.ctl[a.rank];
+  st(W(own, UW_COUNTER2), 0);
+  st(W(own, UW_CLOSE_DEC), 0);
+  if (a.status) st(a.status, 0);
+  if (ld(W(own, UW_ERROR)) != 0) return;
+  u64* openw = W(a.ctl[0], UW_OPEN);
+  u64 w = ld_acq(openw);
+  for (;;) {
+    if ((w & kFrozen) || open_count(w) < 1) return;
+    // a live replica still needs the ring slot: skip this tick
+    if (min_applied(a) < open_u(w) - kUlogRing + 1) return;
+    if (cas(openw, w, w | kFrozen)) break;
+  }
+  const long long u = open_u(w);
+  st(W(own, UW_CLOSE_DEC), (u64)(u + 1));
+  publish_closed(a, u, open_count(w), open_mask(w), 1u << a.rank, 1.f / (float)open_count(w), true);
+}
+
+__global__ __launch_bounds__(256) void ulog_close_reduce_kernel(UlogArgs a) {
+  __shared__ int s_last;
+  u64* own = a.ctl[a.rank];
+  const u64 dec = ld(W(own, UW_CLOSE_DEC));
+  if (!dec) return;
+  const long long u = (long long)dec - 1;
+  Rec r;
+  if (read_hist(own, u, r) != 1) return;
+  const int slot = (int)(u % kUlogRing);
+  const long long n4 = a.n >> 2;
+  const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long gstride = (long long)gridDim.x * blockDim.x;
+  floatx4* out = reinterpret_cast<floatx4*>(a.red[a.rank]) + (long long)slot * n4;
+  for (long long i = gtid; i < n4; i += gstride) {
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < a.world; ++q)
+      if ((r.mask >> q) & 1u) acc += __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(a.stage[q]) + i);
+    out[i] = acc;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const u64 prev = __hip_atomic_fetch_add(W(own, UW_COUNTER2), 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = prev == gridDim.x - 1;
+    if (s_last) {
+      __threadfence_system();
+      for (int p = 0; p < a.world; ++p) st_rel(W(a.ctl[p], UW_READY + slot * kUlogMaxPeers + a.rank), (u64)(u + 1));
+      if (a.status) st_rel(a.status, (u64)(u + 1));
+    }
+  }
+}
+
+__global__ void ulog_init_kernel(u64* ctl, long long u0) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  st(W(ctl, UW_OPEN), make_open(u0, 0, 0, false));
+  st(W(ctl, UW_VERSION), (u64)u0);
+  for (int p = 0; p < kUlogMaxPeers; ++p) st(W(ctl, UW_APPLIED + p), (u64)u0);
+  st(W(ctl, UW_STATS + US_VERSION), (u64)u0);
+}
+
+__global__ void ulog_mark_dead_kernel(u64* ctl, unsigned mask) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  __hip_atomic_fetch_or(W(ctl, UW_DEAD), (u64)mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void validate(const UlogArgs& a, int blocks, bool needs_optimizer) {
+  if (a.world < 1 || a.world > kUlogMaxPeers || a.rank < 0 || a.rank >= a.world) throw std::runtime_error("update log: bad rank/world");
+  if (a.n <= 0 || (a.n & 3)) throw std::runtime_error("update log: n must be a positive multiple of 4");
+  if (blocks < 1 || blocks > kUlogMaxBlocks) throw std::runtime_error("update log: 1..128 blocks (all must be co-resident)");
+  for (int p = 0; p < a.world; ++p)
+    if (!a.ctl[p] || !a.stage[p] || !a.red[p]) throw std::runtime_error("update log: unmapped peer buffer");
+  if (a.timeout_ticks <= 0) throw std::runtime_error("update log: timeout must be positive");
+  if (needs_optimizer) {
+    if (!a.grads || !a.p || !a.m || (a.opt == ULOG_ADAM && !a.v)) throw std::runtime_error("update log: null gradient / parameter / slot pointer");
+    if (a.mode < ULOG_CONTRIBUTE || a.mode > ULOG_SKIP) throw std::runtime_error("update log: bad mode");
+    if (a.mode == ULOG_CONTRIBUTE && (a.quorum < 1 || a.quorum > a.world)) throw std::runtime_error("update log: quorum must be 1..world");
+  }
+}
+
+}  // namespace
+
+void ulog_step(const UlogArgs& a, int blocks, hipStream_t stream) {
+  validate(a, blocks, true);
+  launch("ulog_begin", ulog_begin_kernel, dim3(1), dim3(64), 0, stream, a);
+  launch("ulog_step", ulog_step_kernel, dim3(blocks), dim3(256), 0, stream, a);
+}
+
+void ulog_close(const UlogArgs& a, int blocks, hipStream_t stream) {
+  validate(a, blocks, false);
+  launch("ulog_close_begin", ulog_close_begin_kernel, dim3(1), dim3(64), 0, stream, a);
+  launch("ulog_close_reduce", ulog_close_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
+}
+
+void ulog_init_ctl(unsigned long long* ctl, long long u0, hipStream_t stream) {
+  if (!ctl) throw std::runtime_error("update log: null control block");
+  hipLaunchKernelGGL(ulog_init_kernel, dim3(1), dim3(64), 0, stream, ctl, u0);
+  DTF_HIP_CHECK(hipGetLastError());
+}
+
+void ulog_mark_dead(unsigned long long* ctl, unsigned mask, hipStream_t stream) {
+  if (!ctl) throw std::runtime_error("update log: null control block");
+  hipLaunchKernelGGL(ulog_mark_dead_kernel, dim3(1), dim3(64), 0, stream, ctl, mask);
+  DTF_HIP_CHECK(hipGetLastError());
+}
+
+void ulog_peek(const unsigned long long* ctl, int first, int count, unsigned long long* out) {
+  if (!ctl || first < 0 || count < 1 || first + count > UW_COUNT) throw std::runtime_error("update log: bad peek range");
+  for (int k = 0; k < count; ++k)
+    DTF_HIP_CHECK(hipMemcpy(out + k, ctl + (size_t)(first + k) * kUlogWordStride, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+}
+
+void ulog_poke(unsigned long long* ctl, int word, unsigned long long value) {
+  if (!ctl || word < 0 || word >= UW_COUNT) throw std::runtime_error("update log: bad poke word");
+  DTF_HIP_CHECK(hipMemcpy(ctl + (size_t)word * kUlogWordStride, &value, sizeof(value), hipMemcpyHostToDevice));
+}
+
+}  // namespace dtf

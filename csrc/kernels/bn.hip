@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(BnReluBwdReduce
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdApplyArgs a) {
+  DTF_ABORT_GUARD(a);
   extern __shared__ float sh[];  // k1[C] (=gamma*rstd), mean[C], rstd[C], mg[C], mgx[C]
   const int C = a.C, C4 = C >> 2;
   float* k1 = sh;

@@ -116,3 +116,17 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 // Launch plumbing: every host-side launcher goes through dtf::launch so that a recording
 // Program (csrc/runtime/program.h) can capture the launch instead of issuing it.
 #include "../runtime/program.h"
+
+namespace dtf {
+// True when the replica's current update is already complete (see AbortRef). Both words live in
+// memory that other GPUs write, so they are read past the caches; the verdict is uniform over the
+// grid in practice and any mix of early and late readers is harmless: a kernel either runs or
+// leaves its outputs at the zeros the step prologue wrote.
+__device__ __forceinline__ bool dtf_aborted(const AbortRef& r) {
+  if (!r.stop) return false;
+  const unsigned long long s = __hip_atomic_load(r.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long v = __hip_atomic_load(r.version, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return s > v;
+}
+}  // namespace dtf
+#define DTF_ABORT_GUARD(args) do { if (dtf::dtf_aborted((args).abort)) return; } while (0)

@@ -52,6 +52,7 @@ struct ConvFpropArgs {
   // statistics accumulated over the written tensor (nullable, [kStatSlots][2*Cout]): for forward
   // the per-channel sum and sum of squares of `out`; for EPI_MASK the sums of g and g*xhat.
   double* out_sums;
+  AbortRef abort;   // short-circuit reference, filled in by the launch dispatcher
 };
 
 // ks in {3,5}; cin_pad in {4,16,32,64}; launches over all B images.
@@ -98,6 +99,7 @@ struct ConvWgradArgs {
   int co_tiles;          // 16-channel output tiles per block (0: chosen by the launcher)
   int debug_skip;        // timing experiments only: 1 = no MFMA, 2 = no loads, 4 = no flush
   unsigned long long* dbg_stamps;  // timing experiments only: [blocks][16] wall-clock stamps of thread 0
+  AbortRef abort;   // short-circuit reference, filled in by the launch dispatcher
 };
 size_t conv_wgrad(ConvWgradArgs a, int ks, hipStream_t stream);
 // Band-tiled persistent variant for the 3x3 ResNet shapes; returns 0 when the shape is not covered.
@@ -145,6 +147,7 @@ struct ConvBwdFusedArgs {
   // neighbour process) the remaining blocks pick up the work instead of the grid waiting for the
   // slow blocks' fixed share. nullptr = static striding.
   int* tile_counters;
+  AbortRef abort;   // short-circuit reference, filled in by the launch dispatcher
 };
 constexpr int kBwdTileCounters = 32;   // 8 XCDs x up to 4 channel splits
 bool conv_bwd_fused_supported(int B, int H, int W, int C);
@@ -172,6 +175,7 @@ struct ConvStemArgs {
   const double* dy_gsums;  // [kStatSlots][32]
   float* dy_dgamma;        // [16], nullable
   float* dy_dbeta;         // [16], nullable
+  AbortRef abort;   // short-circuit reference, filled in by the launch dispatcher
 };
 bool conv_stem_supported(int H, int W, int Cin, int Cout, int ks, int stride);
 void conv_stem_fwd(const ConvStemArgs& a, hipStream_t stream);
@@ -200,6 +204,7 @@ struct Conv5x5Args {
   // winner positions (maxpool2x2_fwd's encoding); the activation itself is not written.
   float* pool_out;
   unsigned char* pool_arg_out;
+  AbortRef abort;   // short-circuit reference, filled in by the launch dispatcher
 };
 struct Conv5x5PackArgs {
   const float* w;   // [25][Cin][Cout]
@@ -222,6 +227,7 @@ struct Conv5x5WgradArgs {
   // stores instead of adding it to dw (no atomics; sum the conv5x5_wgrad_parts(B) copies with
   // partial_sum). Every element is written, so the buffer needs no clearing.
   float* partials;
+  AbortRef abort;   // short-circuit reference, filled in by the launch dispatcher
 };
 int conv5x5_wgrad_parts(int B);
 void conv5x5_wgrad(const Conv5x5WgradArgs& a, hipStream_t stream);

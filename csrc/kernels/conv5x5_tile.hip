@@ -76,6 +76,7 @@ struct C5 {
 // x [B,14,14,CIN]; w [25][COUT][CIN] (FLIP: tap t reads w[24-t]); y [B,14,14,COUT].
 template <int CIN, int COUT, int IMGS, bool FLIP, bool BIAS_RELU, bool POOLED, bool POOLOUT>
 __global__ __launch_bounds__(256) void conv5x5_tile_kernel(Conv5x5Args a) {
+  DTF_ABORT_GUARD(a);
   using G = C5<CIN, COUT, IMGS>;
   static_assert(!POOLED || (CIN == 64 && IMGS == 1), "pooled staging is the data-gradient form");
   static_assert(!POOLOUT || (BIAS_RELU && COUT == 64), "the fused max pool follows the forward form");
@@ -298,6 +299,7 @@ constexpr int kWgNpfX = (kWgXChunks + 255) / 256, kWgNpfY = (kWgYChunks + 255) /
 
 template <bool POOLED>
 __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(Conv5x5WgradArgs a) {
+  DTF_ABORT_GUARD(a);
   extern __shared__ __align__(16) float lds[];
   float* sx = lds;
   float* sy = lds + kWgXFloats;

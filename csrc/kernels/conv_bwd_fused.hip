@@ -75,6 +75,7 @@ struct BF {
 
 template <int C, int NT, int TW, int TH, bool DYBN, int RES = 0>   // RES: 0 none, 1 identity shortcut, 2 option-A shortcut
 __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs a) {
+  DTF_ABORT_GUARD(a);
   static_assert(!RES || DYBN, "the shortcut term rides on the BatchNorm prologue");
   using G = BF<C, NT, TW, TH>;
   constexpr int CPP = G::CPP, XC = G::XC, XPP = G::XPP, CG = G::CG, KG = G::KG, LW = G::LW;

@@ -44,6 +44,7 @@ struct DS2 {
 
 template <int CP, int NT, int TW, int TH>
 __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_kernel(ConvFpropArgs a) {
+  DTF_ABORT_GUARD(a);
   using G = DS2<CP, NT, TW, TH>;
   constexpr int CPP = G::CPP, CG = G::CG, C4 = G::C4, LW = G::LW;
   extern __shared__ __attribute__((aligned(16))) float smem[];

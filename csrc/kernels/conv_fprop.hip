@@ -30,6 +30,7 @@ __device__ __forceinline__ int round_up4(int v) { return (v + 3) & ~3; }
 
 template <int KS, int S, int CP, int NT, int MTW>
 __global__ __launch_bounds__(256) void conv_fprop_kernel(ConvFpropArgs a) {
+  DTF_ABORT_GUARD(a);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int CPP = CP + 4;
   constexpr int KG = KGroups<KS, CP>::value;

@@ -51,6 +51,7 @@ struct FBand {
 
 template <int S, int CP, int NT, int TW, int TH, bool UPS, bool BWD>
 __global__ __launch_bounds__(256, 2) void conv_fprop_band_kernel(ConvFpropArgs a) {
+  DTF_ABORT_GUARD(a);
   using G = FBand<S, CP, NT, TW, TH, UPS>;
   constexpr int CPP = G::CPP, CG = G::CG, KG = G::KG, C4 = G::C4, LW = G::LW, MTW = G::MTW;
   extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -48,6 +48,7 @@ struct PP {
 
 template <int CP, int NT, int TW, int TH, bool BWD>
 __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(ConvFpropArgs a) {
+  DTF_ABORT_GUARD(a);
   using G = PP<CP, NT, TW, TH>;
   constexpr int CPP = G::CPP, CG = G::CG, KG = G::KG, C4 = G::C4, LW = G::LW, MTW = G::MTW, ITER = G::ITER;
   extern __shared__ __attribute__((aligned(16))) float smem[];

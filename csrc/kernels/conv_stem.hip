@@ -49,6 +49,7 @@ __device__ __forceinline__ float4 stem_fetch(const float* x, int tile, int tid) 
 }
 
 __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(ConvStemArgs a) {
+  DTF_ABORT_GUARD(a);
   __shared__ __align__(16) float plane[2][kPlane];
   __shared__ float scratch[4 * 2 * 16];
   const int tid = threadIdx.x;
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(ConvStemArgs a) {
 // DYBN: dy is staged as ca * dy + cb * y + cc per channel (BatchNorm backward of the layer after the stem)
 template <bool DYBN>
 __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(ConvStemArgs a) {
+  DTF_ABORT_GUARD(a);
   constexpr int DS = 20;   // dy pixel stride in LDS (16 + 4: four pixels of a k-step start 16 banks apart)
   __shared__ __align__(16) float plane[2][kPlane];
   __shared__ __align__(16) float sdy[2][kTH * kW * DS];

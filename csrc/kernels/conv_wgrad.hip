@@ -21,6 +21,7 @@ __device__ __forceinline__ int round_up4(int v) { return (v + 3) & ~3; }
 
 template <int KS, int S, int CP, int CO_T>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgradArgs a) {
+  DTF_ABORT_GUARD(a);
 #define DTF_STAMP(k) do { if (a.dbg_stamps && threadIdx.x == 0) a.dbg_stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = wall_clock64(); } while (0)
   DTF_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) float smem[];

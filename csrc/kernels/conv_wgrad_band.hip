@@ -56,6 +56,7 @@ struct BandGeom {
 
 template <int S, int CP, int CO_T, int TW, int TH>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(ConvWgradArgs a) {
+  DTF_ABORT_GUARD(a);
   using G = BandGeom<S, CP, CO_T, TW, TH>;
   constexpr int CPP = G::CPP, CO_B = G::CO_B, COP = G::COP, CI_T = G::CI_T;
   constexpr int WP = G::WP, WX = G::WX, PPW = G::PPW, NA = G::NA, NB = G::NB;

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void add_relu_bwd_kernel(AddReluBwdArgs a) {
 }
 
 __global__ __launch_bounds__(256) void relu_bwd_kernel(ReluMaskArgs a) {
+  DTF_ABORT_GUARD(a);
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride)
     a.dx[i] = a.y[i] > 0.f ? a.dy[i] : 0.f;
@@ -154,6 +155,7 @@ __device__ __forceinline__ void philox_round(uint32_t (&ctr)[4], uint32_t k0, ui
 }
 
 __global__ __launch_bounds__(256) void dropout_kernel(DropoutArgs a) {
+  DTF_ABORT_GUARD(a);
   const long long n4 = (a.n + 3) >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   const float inv_keep = 1.f / a.keep_prob;
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(DropoutArgs a) {
 }
 
 __global__ __launch_bounds__(256) void col_sum_kernel(ColSumArgs a) {
+  DTF_ABORT_GUARD(a);
   extern __shared__ float red[];
   for (int c = threadIdx.x; c < a.C; c += blockDim.x) red[c] = 0.f;
   __syncthreads();

@@ -22,9 +22,11 @@ struct GemmKArgs {
   GemmArgs g;
   int k_per_split;
   int atomic_out;
+  AbortRef abort;
 };
 
 __global__ __launch_bounds__(256) void gemm_kernel(GemmKArgs ka) {
+  DTF_ABORT_GUARD(ka);
   const GemmArgs& a = ka.g;
   __shared__ __attribute__((aligned(16))) float As[BM * LDT];
   __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
@@ -168,6 +170,7 @@ struct Tile128 {
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm128_kernel(GemmKArgs ka) {
+  DTF_ABORT_GUARD(ka);
   const GemmArgs& a = ka.g;
   using TileA = Tile128<!TA>;   // A [M,K] row-major is k-contiguous; trans_a stores [K,M]
   using TileB = Tile128<TB>;    // B [K,N] row-major is n-contiguous; trans_b stores [N,K]
@@ -239,8 +242,9 @@ __global__ __launch_bounds__(256) void gemm128_kernel(GemmKArgs ka) {
       }
 }
 
-struct BiasActArgs { float* C; const float* bias; int M, N, ldc, relu; };
+struct BiasActArgs { float* C; const float* bias; int M, N, ldc, relu; AbortRef abort; };
 __global__ __launch_bounds__(256) void bias_act_kernel(BiasActArgs a) {
+  DTF_ABORT_GUARD(a);
   const long long total = (long long)a.M * a.N;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {

@@ -49,6 +49,7 @@ __device__ __forceinline__ floatx4 group_sum(floatx4 v, int C4) {
 }
 
 __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
+  DTF_ABORT_GUARD(a);
   __shared__ float s_scale[kMaxC], s_shift[kMaxC];
   __shared__ float s_w[kMaxC * kMaxK / 4];
   const int C = a.C, C4 = C >> 2, K = a.K, tid = threadIdx.x;
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadFwdArgs a) {
 }
 
 __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
+  DTF_ABORT_GUARD(a);
   __shared__ float s_scale[kMaxC], s_shift[kMaxC], s_mean[kMaxC], s_rstd[kMaxC];
   __shared__ float s_w[kMaxC * kMaxK / 4];
   __shared__ float s_red[2 * kMaxC];
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
 // feat[n][c] * dz[n][k], db[k] = sum_n dz[n][k]. The batch is split over gridDim.y blocks that
 // combine with one atomic per element.
 __global__ __launch_bounds__(256) void head_param_grad_kernel(HeadBwdArgs a) {
+  DTF_ABORT_GUARD(a);
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int C = a.C, K = a.K;
   const int per = (a.B + gridDim.y - 1) / gridDim.y;
@@ -227,6 +230,7 @@ __global__ __launch_bounds__(256) void head_param_grad_kernel(HeadBwdArgs a) {
 }
 
 __global__ __launch_bounds__(256) void softmax_xent_kernel(SoftmaxXentArgs a) {
+  DTF_ABORT_GUARD(a);
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   float loss = 0.f;
   int hit = 0;

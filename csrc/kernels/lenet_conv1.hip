@@ -51,6 +51,7 @@ __device__ __forceinline__ void load_patch(const float* plane, int cell, float (
 }
 
 __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(Conv1PoolFwdArgs a) {
+  DTF_ABORT_GUARD(a);
   __shared__ __align__(16) float plane[2][kPlane];
   const int tid = threadIdx.x;
   const int co = tid & 31, sub = tid >> 5;
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(Conv1PoolFwdArgs a)
 }
 
 __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(Conv1PoolBwdArgs a) {
+  DTF_ABORT_GUARD(a);
   __shared__ __align__(16) float plane[2][kPlane];
   __shared__ float red[4][26][kCo];
   const int tid = threadIdx.x;

@@ -56,6 +56,7 @@ struct BnBwdApplyArgs {
   int res_mode;
   const float* res;     // IDENT: [n_rows, C]; SHORTCUT_A: gradient of the block output [B,H/2,W/2,2C]
   int H, W;             // spatial dims of x (needed for SHORTCUT_A)
+  AbortRef abort;   // short-circuit reference, filled in by the launch dispatcher
 };
 void bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t stream);
 
@@ -74,6 +75,7 @@ struct HeadFwdArgs {
   int* correct;         // [slots] += number of top-1 hits, spread the same way (nullable)
   int B, HW, C, K;
   int slots;            // power of two; one atomic target for 1024 blocks serialises them (~25 ns each)
+  AbortRef abort;   // short-circuit reference, filled in by the launch dispatcher
 };
 void head_fwd(const HeadFwdArgs& a, hipStream_t stream);
 
@@ -88,6 +90,7 @@ struct HeadBwdArgs {
   float* d_fc_w;         // [C, K] +=
   float* d_fc_b;         // [K] +=
   int B, HW, C, K;
+  AbortRef abort;   // short-circuit reference, filled in by the launch dispatcher
 };
 void head_bwd(const HeadBwdArgs& a, hipStream_t stream);
 
@@ -100,6 +103,7 @@ struct SoftmaxXentArgs {
   float* loss;          // [1] +=
   int* correct;         // [1] += nullable
   int B, K;
+  AbortRef abort;   // short-circuit reference, filled in by the launch dispatcher
 };
 void softmax_xent(const SoftmaxXentArgs& a, hipStream_t stream);
 
@@ -141,7 +145,7 @@ struct SlotReduceArgs { float* y; float* slots; long long n; long long slot_stri
 void slot_reduce(const SlotReduceArgs& a, hipStream_t stream);
 // y[0:n] += sum over p < parts of ws[p*stride + (0:n)] (per-workgroup partial results written with
 // plain stores; n and stride multiples of 4).
-struct PartialSumArgs { float* y; const float* ws; long long n; int parts; long long stride; };
+struct PartialSumArgs { float* y; const float* ws; long long n; int parts; long long stride; AbortRef abort; };
 void partial_sum(const PartialSumArgs& a, hipStream_t stream);
 
 struct AddReluArgs { const float* a; const float* b; float* out; long long n; int relu_first; };
@@ -167,16 +171,16 @@ void maxpool2x2_bwd(const MaxPoolBwdArgs& a, hipStream_t stream);
 // position arg (same encoding as maxpool2x2_fwd). Backward adds the filter gradient [25][32] and
 // the bias gradient [32] computed from the pooled gradient dp; with slot_stride != 0 they go to
 // the copy of the block's XCD (dw + slot * slot_stride, dbias + slot * slot_stride).
-struct Conv1PoolFwdArgs { const float* x; const float* w; const float* bias; float* p; unsigned char* arg; int B; };
+struct Conv1PoolFwdArgs { const float* x; const float* w; const float* bias; float* p; unsigned char* arg; int B; AbortRef abort; };
 void conv1_pool_fwd(const Conv1PoolFwdArgs& a, hipStream_t stream);
 struct Conv1PoolBwdArgs { const float* x; const float* dp; const unsigned char* arg; const float* p; float* dw; float* dbias;
-                          int slot_stride; int B; };
+                          int slot_stride; int B; AbortRef abort; };
 void conv1_pool_bwd(const Conv1PoolBwdArgs& a, hipStream_t stream);
 
 // dropout with a counter-based Philox-4x32-10 stream: mask regenerated from (seed, offset)
 // in backward (reference: DistributedLeNet/src/mnist.py:139-140, keep_prob 0.5, seed 66478)
 struct DropoutArgs { const float* x; float* y; long long n; float keep_prob; unsigned long long seed; unsigned long long offset;
-                     const unsigned long long* offset_dev; };   // offset_dev (nullable): added to offset, read at run time so a replayed program draws a new mask per step
+                     const unsigned long long* offset_dev; AbortRef abort; };   // offset_dev (nullable): added to offset, read at run time so a replayed program draws a new mask per step
 void dropout_apply(const DropoutArgs& a, hipStream_t stream);   // same kernel for fwd (x) and bwd (dy)
 
 // fp32 GEMM on MFMA: C[M,N] = op(A) * op(B) (+bias[N]) (relu) ; row-major storage
@@ -187,12 +191,13 @@ struct GemmArgs {
   int trans_a, trans_b;   // trans_a: A stored [K,M]; trans_b: B stored [N,K]
   int relu;
   int accumulate;         // C += result
+  AbortRef abort;   // short-circuit reference, filled in by the launch dispatcher
 };
 void gemm_f32(const GemmArgs& a, hipStream_t stream);
 
-struct ColSumArgs { const float* x; float* out; long long n_rows; int C; };   // out[C] += column sums
+struct ColSumArgs { const float* x; float* out; long long n_rows; int C; AbortRef abort; };   // out[C] += column sums
 void col_sum(const ColSumArgs& a, hipStream_t stream);
-struct ReluMaskArgs { const float* dy; const float* y; float* dx; long long n; };   // dx = dy * 1[y>0]
+struct ReluMaskArgs { const float* dy; const float* y; float* dx; long long n; AbortRef abort; };   // dx = dy * 1[y>0]
 void relu_bwd(const ReluMaskArgs& a, hipStream_t stream);
 
 // evaluation / summaries

@@ -6,6 +6,7 @@
 // the mean of the aggregated replicas) are read from a small device buffer so that a captured
 // hipGraph can be replayed with new values.
 #include "ops.h"
+#include "optim_math.h"
 
 namespace dtf {
 namespace {
@@ -27,13 +28,7 @@ __global__ __launch_bounds__(256) void adam_kernel(FlatOptArgs a) {
   floatx4* v4 = reinterpret_cast<floatx4*>(a.v);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     floatx4 p = p4[i], m = m4[i], v = v4[i];
-    const floatx4 g = g4[i] * gs;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      m[e] = b1 * m[e] + (1.f - b1) * g[e];
-      v[e] = b2 * v[e] + (1.f - b2) * g[e] * g[e];
-      p[e] -= lr_t * m[e] / (sqrtf(v[e]) + eps);
-    }
+    adam_update4(p, m, v, g4[i], gs, lr_t, b1, b2, eps);
     p4[i] = p;
     m4[i] = m;
     v4[i] = v;
@@ -61,9 +56,7 @@ __global__ __launch_bounds__(256) void momentum_kernel(FlatOptArgs a) {
   floatx4* m4 = reinterpret_cast<floatx4*>(a.m);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     floatx4 p = p4[i], m = m4[i];
-    const floatx4 g = g4[i] * gs + p * wd;
-    m = m * mu + g;
-    p -= m * lr;
+    momentum_update4(p, m, g4[i], gs, lr, mu, wd);
     p4[i] = p;
     m4[i] = m;
   }
@@ -144,6 +137,7 @@ __global__ __launch_bounds__(256) void slot_reduce_kernel(SlotReduceArgs a) {
 // loads in flight; a single group stores, several groups add atomically (y is an accumulator).
 constexpr int kPartGroup = 32;
 __global__ __launch_bounds__(256) void partial_sum_kernel(PartialSumArgs a) {
+  DTF_ABORT_GUARD(a);
   const long long n4 = a.n >> 2;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;

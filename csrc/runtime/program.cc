@@ -10,6 +10,11 @@ Program*& current_recorder() {
   return rec;
 }
 
+AbortRef& current_abort_ref() {
+  static thread_local AbortRef ref;
+  return ref;
+}
+
 void ensure_dynamic_lds(const void* fn, size_t shmem) {
   // Kernels asking for more than the default dynamic LDS window must raise the function's
   // limit once. Remember the largest request per kernel.

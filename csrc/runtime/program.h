@@ -26,6 +26,27 @@ namespace dtf {
       throw std::runtime_error(std::string(#expr) + " failed: " + hipGetErrorString(_e)); \
   } while (0)
 
+// Short-circuit reference carried by the kernels of a training step (kernel argument structs
+// with a member `abort` get it from the launch dispatcher): a kernel whose `stop` word has risen
+// above the replica's `version` word returns at once, so once the update a replica works for is
+// complete, the rest of its forward / backward pass costs launch latency only and leaves zeros in
+// the gradients it did not reach (reference: every backward op wrapped in a stop check,
+// DistributedLeNet/src/short_circuit_gradients.py:487-545). Null pointers (the default) disable it
+// at no cost: the pointers are kernel arguments.
+struct AbortRef {
+  const unsigned long long* stop = nullptr;     // e + 1 once update e has all the gradients it will take
+  const unsigned long long* version = nullptr;  // updates this replica has applied
+};
+// The reference given to kernels launched or recorded from this thread (default: disabled).
+AbortRef& current_abort_ref();
+
+namespace detail {
+template <typename A>
+inline auto set_abort(A& a, int) -> decltype(a.abort, void()) { a.abort = current_abort_ref(); }
+template <typename A>
+inline void set_abort(A&, long) {}
+}  // namespace detail
+
 struct LaunchRecord {
   enum Kind { KERNEL = 0, MEMSET = 1, MEMCPY = 2, SYNC = 3 } kind = KERNEL;
   std::string name;
@@ -103,7 +124,9 @@ inline void launch(const char* name, void (*kernel)(Args), dim3 grid, dim3 block
   r.block = block;
   r.shmem = shmem;
   r.args.resize(sizeof(Args));
-  std::memcpy(r.args.data(), &args, sizeof(Args));
+  Args with_abort = args;
+  detail::set_abort(with_abort, 0);
+  std::memcpy(r.args.data(), &with_abort, sizeof(Args));
   ensure_dynamic_lds(r.fn, shmem);
   if (Program* p = current_recorder()) {
     p->push(std::move(r));

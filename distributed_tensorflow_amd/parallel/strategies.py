@@ -237,12 +237,13 @@ class Interval(_LogStrategy):
         done = log.forward_backward(replica, abortable=False)
         dt = time.time() - t0
         res = log.contribute_open(lr, self.max_staleness)
-        return self._result(res, done, self.board.agg_open_count(), dt)
+        return self._result(res, done, log.contributors_hint(), dt)
 
     def finish(self) -> None:
         if self.log is not None:
-            self.log.finish()
-        self.stop_interval_updates()
+            self.comm.barrier()            # nobody pushes any more
+            self.stop_interval_updates()   # chief: no window closes after this
+            self.comm.barrier()
         super().finish()
 
 
@@ -300,7 +301,7 @@ class Weighted(_LogStrategy):
             return self._plain_step(replica, lr, t0)
         log = self._get_log(replica)
         # the kill draw belongs to the UPDATE (identical on every replica whatever its iteration count)
-        w = self.weights_for_step(log.version)
+        w = self.weights_for_step(log.sync_version())
         wr = float(w[self.rank])
         alive = int((w != 0).sum())
         total = float(w.sum())

@@ -102,6 +102,8 @@ class HostUpdateLog:
         self._pending: Optional[Tuple[int, int]] = None   # interval mode: (update, gradients) staged and not yet known closed
         self.dropped = 0
         self.contributed = 0
+        self.max_version = 1 << 60
+        self._last_lr: LrLike = 0.0
         # data regions: every replica creates its own, then maps everybody's
         self._files = [f"{self._name}_stage_{self.rank}", f"{self._name}_red_{self.rank}"]
         _shm_tensor(self._files[0], self.total, True)
@@ -127,6 +129,13 @@ class HostUpdateLog:
 
     def global_version(self) -> int:
         return int(self.board.agg_open_update())
+
+    def sync_version(self) -> int:
+        return self.version
+
+    def contributors_hint(self) -> int:
+        """Gradients in the window that is open now."""
+        return int(self.board.agg_open_count())
 
     def _check(self, ok: bool, what: str) -> None:
         if not ok:
@@ -232,6 +241,7 @@ class HostUpdateLog:
         b = self.board
         a = self.replica.arena
         n = 0
+        self._last_lr = lr
         while True:
             u = self.version
             ent = b.agg_entry(u)
@@ -276,6 +286,8 @@ class HostUpdateLog:
             target = b.agg_open_update() if final_version is None else final_version
             if b.agg_min_applied() >= target:
                 break
+            with self._lock:
+                self.catch_up(self._last_lr)   # this replica may be the one the others are waiting for
             time.sleep(0.001)
 
     def close(self) -> None:

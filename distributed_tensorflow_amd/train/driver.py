@@ -179,6 +179,8 @@ def train(flags, model: str) -> Dict:
         model, batch_size, device, num_residual_blocks=flags.num_residual_blocks, optimizer=flags.optimizer,
         momentum=flags.momentum, weight_decay=flags.weight_decay if flags.optimizer == "momentum" else 0.0,
         num_buckets=buckets, use_graph=flags.hip_graph,
+        # kernels that return at once when the update they work for is complete (GPU replicas)
+        abortable=bool(world > 1 and (flags.soft_kill_method or flags.backup_worker_method)),
     )
     # On the GPU the dataset lives in HBM: ResNet crops + whitens with one kernel per step, LeNet
     # slices its batches device-to-device

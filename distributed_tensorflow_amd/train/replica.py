@@ -174,7 +174,7 @@ class HipReplica(ReplicaBase):
 
     def __init__(self, model: str, batch_size: int, *, num_residual_blocks: int = 18, optimizer: str = "adam",
                  momentum: float = 0.9, weight_decay: float = 0.0, seed: int = 66478, num_buckets: int = 1,
-                 use_graph: bool = True):
+                 use_graph: bool = True, abortable: bool = False):
         from ..models.lenet_hip import LeNetHipStep
         from ..models.resnet_hip import ResNetHipStep
 
@@ -186,11 +186,27 @@ class HipReplica(ReplicaBase):
         self.arena = ParamArena(make_specs(model, num_residual_blocks), self.device, slots)
         self.arena.initialize(seed)
         self.stream = torch.cuda.Stream()
+        # Short-circuiting (reference: DistributedLeNet/src/short_circuit_gradients.py:487-545): the
+        # kernels of the step are recorded with the addresses of two words of a control block that
+        # the update log adopts later; once "updates complete" rises above "updates applied" every
+        # kernel of the step returns at once. Without it the kernels carry null pointers and pay nothing.
+        self.ctl_block = 0
+        if abortable:
+            from ..ops import native as nv
+            from ..parallel.update_log_hip import abort_words, alloc_control_block
+
+            self.ctl_block = alloc_control_block()
+            nv.hip().set_abort_ref(*abort_words(self.ctl_block))
+        try:
+            with torch.cuda.stream(self.stream):
+                if model == "lenet":
+                    self.step = LeNetHipStep(batch_size, self.arena, optimizer=optimizer, num_buckets=num_buckets)
+                else:
+                    self.step = ResNetHipStep(num_residual_blocks, batch_size, self.arena, optimizer=optimizer, num_buckets=num_buckets)
+        finally:
+            if abortable:
+                nv.hip().set_abort_ref(0, 0)
         with torch.cuda.stream(self.stream):
-            if model == "lenet":
-                self.step = LeNetHipStep(batch_size, self.arena, optimizer=optimizer, num_buckets=num_buckets)
-            else:
-                self.step = ResNetHipStep(num_residual_blocks, batch_size, self.arena, optimizer=optimizer, num_buckets=num_buckets)
             # A step that trails its filter gradients on a side stream is issued from C++ on two
             # real streams: hipGraph replay of the forked graph was measured slower (cross-queue
             # dependencies cost ~10 us each).
@@ -310,4 +326,5 @@ def make_replica(model: str, batch_size: int, device: str = "auto", **kw) -> Rep
         kw.pop("device", None)
         return HipReplica(model, batch_size, **kw)
     kw.pop("use_graph", None)
+    kw.pop("abortable", None)
     return TorchReplica(model, batch_size, device="cpu", **kw)

@@ -243,19 +243,23 @@ print("ok")
 def test_queued_steps_keep_their_own_scalars():
     """Steps queued without any host synchronisation must each run with the learning rate and
     gradient scale staged for them (the host runs far ahead of the GPU in the benchmark loop):
-    same parameters as a run that synchronises after every step."""
-    n, batch, steps = 1, 64, 24
+    same parameters, bit for bit, as a run that synchronises after every step. Only the optimizer
+    segment is replayed, on a fixed gradient: the forward/backward pass sums filter gradients with
+    float atomics and Adam amplifies their last-bit differences, which would drown the comparison."""
+    n, batch, steps = 1, 64, 48
 
-    def run(sync_each):
+    def run(sync_each, shift=0):
         step, _, _ = _make(n, batch)
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
-            step.instantiate()
+            step.instantiate(per_segment=True)
+            gen = torch.Generator(device="cuda").manual_seed(11)
+            step.arena.grads.copy_(torch.randn(step.arena.grads.shape, device="cuda", generator=gen))
             for t in range(1, steps + 1):
                 # values that differ a lot from step to step, so a mix-up is visible
-                step.set_hyper(lr_t=ref.adam_lr_t(1e-3, t) * (1.0 + (t % 3)), grad_scale=1.0 / (1 + t % 4))
-                step.set_step_counter(t)
-                step.run(graph=True)
+                k = t + shift
+                step.set_hyper(lr_t=ref.adam_lr_t(1e-3, t) * (1.0 + (k % 3)), grad_scale=1.0 / (1 + k % 4))
+                step.run(step.num_segments - 1, True)
                 if sync_each:
                     s.synchronize()
         s.synchronize()
@@ -263,6 +267,8 @@ def test_queued_steps_keep_their_own_scalars():
 
     synced = run(True)
     queued = run(False)
+    mixed = run(True, shift=1)
+    assert not torch.equal(synced, mixed)        # the yardstick: scalars one step off are visible
     assert torch.equal(synced, queued)
 
 

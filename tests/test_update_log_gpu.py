@@ -1,0 +1,223 @@
+"""Device update log (csrc/comm/update_log.hip): non-blocking aggregation between several replicas
+that share GPU 0 (their control blocks, staging buffers and reduced rings are mapped into each
+other through HIP IPC exactly as between GPUs of one node; gloo carries the set-up exchange)."""
+import os
+import time
+
+import pytest
+import torch
+
+from mp_util import run_workers
+
+pytestmark = pytest.mark.gpu
+
+BATCH = 16
+
+
+def _setup(rank, world, board_name, abortable=False, seed=300):
+    from distributed_tensorflow_amd.parallel import control_plane
+    from distributed_tensorflow_amd.parallel.comm import Communicator
+    from distributed_tensorflow_amd.train.replica import HipReplica
+
+    os.environ["LOCAL_RANK"] = "0"
+    comm = Communicator.from_env(backend="gloo")
+    board = control_plane.open_board(board_name, world, rank)
+    rep = HipReplica("resnet", BATCH, num_residual_blocks=1, num_buckets=1, abortable=abortable)
+    g = torch.Generator().manual_seed(seed + rank)
+    rep.load_batch(torch.randn(BATCH, 32, 32, 3, generator=g), torch.randint(0, 10, (BATCH,), generator=g))
+    control_plane.launch_manager(board, rank, world, 120)
+    return comm, board, rep
+
+
+def _backup_worker(rank, world, board_name, m, slow_rank):
+    from distributed_tensorflow_amd.ops import reference as ref
+    from distributed_tensorflow_amd.parallel.strategies import Backup
+
+    comm, board, rep = _setup(rank, world, board_name, abortable=True)
+    rep.forward_backward()
+    rep.synchronize()
+    own = rep.arena.grads.detach().cpu().clone()
+    gathered = comm.all_gather_object(own)
+    p0 = rep.arena.params.detach().cpu().clone()
+    strat = Backup(comm, board, m)
+    log = strat._get_log(rep)                                # set-up (collective) outside the timed step
+    comm.barrier()
+    if rank == slow_rank:
+        time.sleep(1.5)                                      # the straggler
+    t0 = time.time()
+    res = strat.step(rep, 0, 1e-3)
+    rep.synchronize()
+    dt = time.time() - t0
+    comm.barrier()
+    count, mask, owners, scale = log.entry(0)
+    fast = [r for r in range(world) if r != slow_rank]
+    mean = torch.stack([gathered[r] for r in fast]).mean(0)
+    want = p0.clone()
+    ref.adam_update(want, mean, torch.zeros_like(want), torch.zeros_like(want), ref.adam_lr_t(1e-3, 1))
+    err = float((rep.arena.params.cpu() - want).abs().mean())
+    strat.finish()
+    comm.close()
+    return dict(included=res.included, err=err, mask=mask, count=count, dt=dt, updates=rep.updates_applied, gs=res.global_step,
+                dropped=log.dropped)
+
+
+def test_backup_update_is_the_mean_of_the_first_m_and_nobody_waits_for_the_straggler():
+    world, m, slow = 3, 2, 1
+    out = run_workers(_backup_worker, world, f"dtf_gu_bk_{os.getpid()}", m, slow, timeout=300)
+    assert [o["included"] for o in out] == [True, False, True]
+    assert all(o["mask"] == 0b101 and o["count"] == m for o in out)     # first M arrivals, agreed by all replicas
+    # mean distance to Adam's first step on the mean of the two fresh gradients. The filter gradients
+    # come from float atomics, so recomputing a gradient changes its last bits, and Adam's first step
+    # (lr * sign) turns that into 2 * lr on the few elements whose gradient is ~0: hence the mean.
+    # Including the straggler's gradient would move it to ~1e-4.
+    assert all(o["err"] < 2e-5 for o in out), [o["err"] for o in out]
+    assert all(o["updates"] == 1 and o["gs"] == 1 for o in out)         # the straggler moved on too
+    assert out[slow]["dropped"] == 1
+    # the property that matters: the fast replicas' step does not contain the straggler's 1.5 s
+    assert out[0]["dt"] < 0.75 and out[2]["dt"] < 0.75, [o["dt"] for o in out]
+
+
+def _stress_worker(rank, world, board_name, m, steps):
+    import random
+
+    from distributed_tensorflow_amd.parallel.strategies import Backup
+
+    comm, board, rep = _setup(rank, world, board_name, abortable=True)
+    strat = Backup(comm, board, m)
+    rng = random.Random(7 + rank)
+    included = 0
+    it = 0
+    while True:
+        g = torch.Generator().manual_seed(1000 * it + rank)
+        rep.load_batch(torch.randn(BATCH, 32, 32, 3, generator=g), torch.randint(0, 10, (BATCH,), generator=g))
+        if rng.random() < 0.3:
+            time.sleep(rng.random() * 0.01)                    # uneven load: random per-step delays
+        res = strat.step(rep, it, 1e-3)
+        included += int(res.included)
+        it += 1
+        if res.global_step >= steps:
+            break
+    strat.finish()
+    rep.synchronize()
+    psum = rep.arena.params.double().sum().item()
+    comm.close()
+    return dict(psum=psum, version=rep.updates_applied, included=included, iters=it)
+
+
+def test_backup_stress_uneven_load_keeps_replicas_identical():
+    world, m, steps = 3, 2, 200
+    out = run_workers(_stress_worker, world, f"dtf_gu_bks_{os.getpid()}", m, steps, timeout=600)
+    assert len({o["version"] for o in out}) == 1 and out[0]["version"] >= steps
+    assert len({o["psum"] for o in out}) == 1                 # same updates in the same order everywhere: same bits
+    assert sum(o["included"] for o in out) == m * out[0]["version"]   # every update took exactly M gradients
+
+
+def _interval_worker(rank, world, board_name, interval_ms, slow_rank, run_s):
+    from distributed_tensorflow_amd.parallel.strategies import Interval
+
+    comm, board, rep = _setup(rank, world, board_name)
+    strat = Interval(comm, board, interval_ms)
+    strat._get_log(rep)
+    comm.barrier()
+    t_end = time.time() + run_s
+    pushes = accepted = 0
+    longest = 0.0
+    it = 0
+    while time.time() < t_end:
+        time.sleep((3.0 if rank == slow_rank else 0.6) * interval_ms / 1e3)
+        t0 = time.time()
+        res = strat.step(rep, it, 1e-3)
+        longest = max(longest, time.time() - t0)
+        pushes += 1
+        accepted += int(res.included)
+        it += 1
+    closed_before_finish = strat.windows_closed
+    strat.finish()
+    rep.synchronize()
+    out = dict(pushes=pushes, accepted=accepted, version=rep.updates_applied, closed=closed_before_finish,
+               psum=rep.arena.params.double().sum().item(), longest=longest)
+    comm.close()
+    return out
+
+
+def test_interval_timer_closes_windows_while_workers_never_wait():
+    world, slow, interval_ms, run_s = 3, 2, 100, 3.0
+    out = run_workers(_interval_worker, world, f"dtf_gu_iv_{os.getpid()}", interval_ms, slow, run_s, timeout=300)
+    version = out[0]["version"]
+    assert len({o["version"] for o in out}) == 1
+    assert len({o["psum"] for o in out}) == 1
+    # global_step advances at the timer's rate, not at the slow replica's
+    assert 0.5 * run_s * 1e3 / interval_ms <= version <= 1.3 * run_s * 1e3 / interval_ms, version
+    assert version - 1 <= out[0]["closed"] <= version
+    assert 0.15 * version <= out[slow]["pushes"] <= 0.5 * version, (out[slow]["pushes"], version)
+    assert out[slow]["accepted"] >= out[slow]["pushes"] - 1
+    assert all(o["longest"] < 0.5 for o in out), [o["longest"] for o in out]
+
+
+def test_short_circuit_every_kernel_returns_at_once_when_the_update_is_complete():
+    """One replica, no peers: raising the 'updates complete' word above the replica's version makes
+    every guarded kernel of the recorded step return immediately - gradients stay at the zeros of
+    the step prologue and the step costs launch latency only - and lowering it restores the step."""
+    from distributed_tensorflow_amd.ops import native as nv
+    from distributed_tensorflow_amd.train.replica import HipReplica
+
+    h = nv.hip()
+    rep = HipReplica("resnet", 256, num_residual_blocks=3, num_buckets=1, abortable=True)
+    g = torch.Generator().manual_seed(5)
+    rep.load_batch(torch.randn(256, 32, 32, 3, generator=g), torch.randint(0, 10, (256,), generator=g))
+
+    def timed():
+        rep.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            rep.forward_backward()
+        rep.synchronize()
+        return (time.perf_counter() - t0) / 20
+
+    rep.forward_backward()
+    rep.synchronize()
+    assert float(rep.arena.grads.abs().sum()) > 0 and rep.loss_value() > 0
+    full = timed()
+    h.ulog_poke(rep.ctl_block, int(h.UW_ABORT), 1)            # update 0 is complete; this replica is at version 0
+    rep.forward_backward()
+    rep.synchronize()
+    assert float(rep.arena.grads.abs().sum()) == 0.0 and rep.loss_value() == 0.0
+    cut = timed()
+    assert cut < 0.5 * full, (cut, full)
+    h.ulog_poke(rep.ctl_block, int(h.UW_VERSION), 1)          # the replica applied update 0: back to work
+    rep.forward_backward()
+    rep.synchronize()
+    assert float(rep.arena.grads.abs().sum()) > 0
+
+
+def _soft_kill_worker(rank, world, board_name, k, slow_rank):
+    from distributed_tensorflow_amd.parallel.strategies import SoftKill
+
+    comm, board, rep = _setup(rank, world, board_name, abortable=True)
+    strat = SoftKill(comm, board, k)
+    log = strat._get_log(rep)
+    comm.barrier()
+    if rank == slow_rank:
+        # start after the others have arrived, so the abort word is already up when the pass starts
+        deadline = time.time() + 30
+        while log.open_count() < k and time.time() < deadline:
+            time.sleep(0.01)
+    res = strat.step(rep, 0, 1e-3)
+    rep.synchronize()
+    gsum = float(rep.arena.grads.abs().sum())
+    comm.barrier()
+    entry = log.entry(0)
+    strat.finish()
+    out = dict(gsum=gsum, entry=entry, version=rep.updates_applied, psum=rep.arena.params.double().sum().item(), included=res.included)
+    comm.close()
+    return out
+
+
+def test_soft_kill_straggler_pushes_zeros_and_the_mean_is_over_all_replicas():
+    world, k, slow = 3, 2, 2
+    out = run_workers(_soft_kill_worker, world, f"dtf_gu_sk_{os.getpid()}", k, slow, timeout=300)
+    assert out[slow]["gsum"] == 0.0 and all(out[r]["gsum"] > 0 for r in (0, 1))   # the whole pass was short-circuited
+    assert all(o["included"] for o in out)                                      # zeros are still pushed
+    count, mask, owners, scale = out[0]["entry"]
+    assert count == world and mask == 0b111 and abs(scale - 1.0 / world) < 1e-7
+    assert all(o["version"] == 1 for o in out) and len({o["psum"] for o in out}) == 1
