@@ -66,7 +66,7 @@ def bench_policy(args) -> None:
     as the headline; each step is forward + backward + the policy's aggregation + update)."""
     from distributed_tensorflow_amd.parallel import control_plane
     from distributed_tensorflow_amd.parallel.comm import Communicator
-    from distributed_tensorflow_amd.parallel.strategies import Backup, FullSync
+    from distributed_tensorflow_amd.parallel.strategies import Backup, FullSync, Interval, SoftKill
     from distributed_tensorflow_amd.train.replica import HipReplica
 
     if not torch.cuda.is_available():
@@ -76,11 +76,12 @@ def bench_policy(args) -> None:
     topo = check_topology(args, comm)
     torch.manual_seed(1234 + comm.rank)
     replica = HipReplica("resnet", args.batch, num_residual_blocks=MODELS[args.model], optimizer=args.optimizer,
-                         num_buckets=(args.buckets or 3) if world > 1 else 1, weight_decay=2e-4)
+                         num_buckets=(args.buckets or 3) if world > 1 and args.mode in ("sharded", "async") else 1,
+                         weight_decay=2e-4, abortable=world > 1 and args.mode in ("backup", "soft_kill"))
     with replica.stream_ctx():
         comm.broadcast(replica.arena.params, 0)
     board = None
-    if args.mode in ("backup", "async"):
+    if args.mode in ("backup", "async", "interval", "soft_kill"):
         name = control_plane.board_name_for("bench_" + args.mode, int(os.environ.get("MASTER_PORT", "0")))
         if comm.is_chief:
             board = control_plane.open_board(name, world, 0)
@@ -98,24 +99,84 @@ def bench_policy(args) -> None:
             m = args.aggregate if args.aggregate > 0 else max(1, world - 1)
             strategy = Backup(comm, board, m)
             detail["replicas_to_aggregate"] = strategy.m
+        elif args.mode == "interval":
+            strategy = Interval(comm, board, args.interval_ms)
+            detail["interval_ms"] = args.interval_ms
+        elif args.mode == "soft_kill":
+            strategy = SoftKill(comm, board, args.aggregate if args.aggregate > 0 else max(1, world - 1))
+            detail["should_stop_worker_num"] = strategy.k
         else:
             strategy = FullSync(comm, board, reduce_scatter=True)
-        step_fn = lambda i: strategy.step(replica, i, args.lr)   # noqa: E731
+        if strategy.uses_update_log and world > 1:
+            # the host never waits for the GPU inside the timed loop: the whole policy runs on the device
+            strategy._get_log(replica).sync_status = False
+        straggle_s = args.inject_straggler_ms / 1e3 if comm.rank == world - 1 and world > 1 else 0.0
+        detail["inject_straggler_ms"] = args.inject_straggler_ms
+
+        def step_fn(i):
+            if straggle_s:
+                time.sleep(straggle_s)     # the last rank is slow to even start its step
+            return strategy.step(replica, i, args.lr)
     images = torch.randn(args.batch, 32, 32, 3, device=comm.device)
     labels = torch.randint(0, 10, (args.batch,), device=comm.device)
     replica.load_batch(images, labels)
-    for i in range(args.warmup):
-        step_fn(i)
-    replica.synchronize()
-    comm.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step_fn(args.warmup + i)
-    replica.synchronize()
-    torch.cuda.synchronize()
-    comm.barrier()
-    dt = time.perf_counter() - t0
+    log_obj = strategy._get_log(replica) if args.mode != "async" and strategy.uses_update_log and world > 1 else None
+    if log_obj is None:
+        for i in range(args.warmup):
+            step_fn(i)
+        replica.synchronize()
+        comm.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step_fn(args.warmup + i)
+        replica.synchronize()
+        torch.cuda.synchronize()
+        comm.barrier()
+        dt = time.perf_counter() - t0
+        images_done = args.batch * world * args.steps
+    else:
+        # Update-log policies: replicas do not move in lockstep, so the run is bounded by UPDATES, like
+        # the reference's max_steps on the global step: everybody iterates until `warmup` (untimed),
+        # then until `warmup + steps` updates are applied; nobody contributes beyond that.
+        it = 0
+
+        def run_until(target: int) -> int:
+            nonlocal it
+            log_obj.max_version = target
+            n = 0
+            while log_obj.version < target:       # the mirror in pinned memory: no GPU synchronisation
+                step_fn(it)
+                it += 1
+                n += 1
+                if n % 8 == 0:
+                    replica.synchronize()         # bound how far the host queues ahead of the counters it polls
+            replica.synchronize()
+            return n
+
+        log_obj.sync_status = True
+        run_until(args.warmup)
+        log_obj.sync_status = False               # the host never waits for the GPU inside a timed step
+        comm.barrier()
+        torch.cuda.synchronize()
+        acc0 = log_obj.contributed
+        t0 = time.perf_counter()
+        iters = run_until(args.warmup + args.steps)
+        own_s = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        comm.barrier()
+        dt = time.perf_counter() - t0
+        # per-rank view: how long an iteration took on THIS rank (a non-straggler must not pay for the
+        # straggler) and what became of its gradients
+        rows = comm.all_gather_object(dict(rank=comm.rank, iterations=iters, ms_per_iteration=round(own_s / max(1, iters) * 1e3, 4),
+                                           version=log_obj.sync_version(), accepted=log_obj.contributed - acc0,
+                                           dropped_total=log_obj.dropped))
+        detail["per_rank"] = rows
+        detail["updates_applied"] = args.steps
+        detail["gradients_aggregated"] = sum(r["accepted"] for r in rows)
+        detail["gradients_computed"] = sum(r["iterations"] for r in rows)
+        images_done = args.batch * detail["gradients_aggregated"]   # images whose gradient entered an update
+        strategy.finish()
     final_loss = replica.loss_value()
     if args.mode == "async":
         shards.drain(30.0)
@@ -127,7 +188,7 @@ def bench_policy(args) -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     if comm.is_chief:
-        value = args.batch * world * args.steps / dt
+        value = images_done / dt
         floor = cpu_floor(args.model)
         print(json.dumps({
             "metric": "images/sec (node) ResNet CIFAR-10 %s-SGD" % args.mode,
@@ -172,7 +233,10 @@ def main() -> None:
                                                      "ranks share one GPU to rehearse the multi-rank path")
     ap.add_argument("--allreduce", choices=["rccl", "p2p"], default="rccl",
                     help="gradient all-reduce: RCCL, or the hand-written two-shot kernel over peer-mapped HBM")
-    ap.add_argument("--mode", choices=["sync", "sharded", "backup", "async"], default="sync",
+    ap.add_argument("--inject-straggler-ms", type=float, default=0.0,
+                    help="policy modes: the last rank sleeps this long before every step")
+    ap.add_argument("--interval-ms", type=float, default=5.0, help="interval mode: the chief closes a window this often")
+    ap.add_argument("--mode", choices=["sync", "sharded", "backup", "interval", "soft_kill", "async"], default="sync",
                     help="sync = the headline (all-reduce of every replica's gradient). The others time the framework's "
                          "other aggregation policies through the same replica + strategy objects the training driver uses: "
                          "sharded = reduce-scatter + per-shard optimizer + all-gather; backup = mean of the first "
