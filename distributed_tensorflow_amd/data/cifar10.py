@@ -93,11 +93,15 @@ def whitening_image(image_np: np.ndarray) -> np.ndarray:
 
 
 def random_crop_and_flip(batch_data: np.ndarray, padding_size: int, rng: Optional[np.random.RandomState] = None) -> np.ndarray:
+    """Random 32x32 crop out of each padded image. Offsets are drawn from 0 .. 2*padding_size - 1 like
+    the reference (np.random.randint(low=0, high=2*padding_size), cifar10_input.py:136-137): the
+    last possible position (offset 2*padding_size, the crop flush with the bottom/right edge) is
+    never used there, and is not used here either, so both pipelines sample the same set of crops."""
     rng = rng or np.random
     out = np.zeros((len(batch_data), IMG_SIZE, IMG_SIZE, IMG_DEPTH), dtype=np.float32)
     for i in range(len(batch_data)):
-        x_off = rng.randint(low=0, high=2 * padding_size + 1)
-        y_off = rng.randint(low=0, high=2 * padding_size + 1)
+        x_off = rng.randint(low=0, high=max(1, 2 * padding_size))
+        y_off = rng.randint(low=0, high=max(1, 2 * padding_size))
         out[i] = batch_data[i][x_off:x_off + IMG_SIZE, y_off:y_off + IMG_SIZE, :]
         # horizontal flipping is disabled in the reference (cifar10_input.py:141)
     return out
@@ -209,8 +213,8 @@ class GpuTrainBatcher:
         h = self._host.numpy()
         h[:, 0] = idx
         for i in range(b):   # same draw order as random_crop_and_flip: row offset, then column offset
-            h[i, 1] = self.rng.randint(low=0, high=2 * self.padding + 1)
-            h[i, 2] = self.rng.randint(low=0, high=2 * self.padding + 1)
+            h[i, 1] = self.rng.randint(low=0, high=max(1, 2 * self.padding))
+            h[i, 2] = self.rng.randint(low=0, high=max(1, 2 * self.padding))
         dev = self._host.to(images_out.device, non_blocking=True)
         index = dev[:, 0].contiguous()
         offs = dev[:, 1:3].contiguous()

@@ -54,6 +54,19 @@ class StepResult:
     global_step: Optional[int] = None   # updates applied so far (None: one more than before iff `applied`)
 
 
+@dataclass
+class PendingGradients:
+    """What `compute_gradients` hands to `apply_gradients`: the replica whose arena holds the
+    gradient, when the step began, and what the policy already knows about it."""
+    replica: object
+    t0: float
+    done: bool = True          # False: the backward pass was cut short
+    compute_s: float = 0.0
+    weight: float = 1.0        # Weighted: this replica's least-squares weight for the update
+    alive: int = 0             # Weighted: replicas not killed for the update
+    total_weight: float = 0.0
+
+
 class Strategy:
     name = "base"
     needs_abort_points = False
@@ -67,7 +80,17 @@ class Strategy:
         self.log = None
         self.start_version = 0   # set by the driver after a checkpoint restore, before the first step
 
-    def step(self, replica, step: int, lr: LrLike) -> StepResult:  # pragma: no cover - interface
+    def step(self, replica, step: int, lr: LrLike) -> StepResult:
+        """One training step: forward + backward, then aggregation + update."""
+        return self.apply_gradients(self.compute_gradients(replica, lr), lr)
+
+    # The two halves of a step, for driver code written like the reference's
+    # (grads = opt.compute_gradients(loss); opt.apply_gradients(grads, worker_id, global_step);
+    # reference: DistributedLeNet/src/distributed_train.py:188-199).
+    def compute_gradients(self, replica, lr: LrLike = 0.0) -> PendingGradients:  # pragma: no cover - interface
+        raise NotImplementedError
+
+    def apply_gradients(self, pending: PendingGradients, lr: LrLike) -> StepResult:  # pragma: no cover - interface
         raise NotImplementedError
 
     def finish(self) -> None:
@@ -87,14 +110,22 @@ class Strategy:
             self.log = make_update_log(replica, self.comm, self.board, self.start_version)
         return self.log
 
-    def _plain_step(self, replica, lr: LrLike, t0: float) -> StepResult:
-        """One replica, or nothing to drop: forward + backward + (all-reduce) + update."""
+    def _plain(self) -> bool:
+        """One replica, or no control board: nothing to drop, the step is the plain synchronous one."""
+        return self.world == 1 or self.board is None
+
+    def _plain_compute(self, replica) -> PendingGradients:
+        """Forward + backward with the bucketed all-reduce overlapped."""
+        t0 = time.time()
         replica.forward_backward(on_bucket=self._bucket_reduce(replica))
-        dt = time.time() - t0
+        return PendingGradients(replica, t0, True, time.time() - t0)
+
+    def _plain_apply(self, pending: PendingGradients, lr: LrLike) -> StepResult:
+        replica = pending.replica
         with replica.stream_ctx():
             self.comm.wait_all()
         replica.apply_update(lr_at(lr, replica.updates_applied), grad_scale=1.0 / self.world)
-        return StepResult(True, self.world, False, True, dt, replica.updates_applied)
+        return StepResult(True, self.world, False, True, pending.compute_s, replica.updates_applied)
 
     def _bucket_reduce(self, replica):
         """Callback for forward_backward(on_bucket=...): buckets become final from the end of the
@@ -117,22 +148,27 @@ class FullSync(Strategy):
         super().__init__(comm, board)
         self.reduce_scatter = reduce_scatter
 
-    def step(self, replica, step: int, lr: LrLike) -> StepResult:
-        t0 = time.time()
+    def compute_gradients(self, replica, lr: LrLike = 0.0) -> PendingGradients:
         if self.reduce_scatter and self.world > 1:
-            return self._step_sharded(replica, lr_at(lr, replica.updates_applied), t0)
-        return self._plain_step(replica, lr, t0)
+            t0 = time.time()
+            replica.forward_backward()
+            return PendingGradients(replica, t0, True, time.time() - t0)
+        return self._plain_compute(replica)
 
-    def _step_sharded(self, replica, lr: float, t0: float) -> StepResult:
+    def apply_gradients(self, pending: PendingGradients, lr: LrLike) -> StepResult:
+        if self.reduce_scatter and self.world > 1:
+            return self._apply_sharded(pending, lr_at(lr, pending.replica.updates_applied))
+        return self._plain_apply(pending, lr)
+
+    def _apply_sharded(self, pending: PendingGradients, lr: float) -> StepResult:
         """Reduce-scatter + sharded optimizer + all-gather, ONE collective each way: every rank
         owns an equal contiguous 1/N of the (padded) parameter and optimizer-slot buffers, reduces
         only that range of the gradient, updates it, and the updated ranges are gathered back.
         Moves the same bytes as the all-reduce but the optimizer reads 1/N of the state per rank;
         it is also the layout of the asynchronous parameter shards (parallel/async_ps.py)."""
+        replica, dt = pending.replica, pending.compute_s
         a = replica.arena
         shard = a.shard_size(self.world)
-        replica.forward_backward()
-        dt = time.time() - t0
         lo, hi = self.rank * shard, (self.rank + 1) * shard
         with replica.stream_ctx():
             self.comm.reduce_scatter_flat(a.padded("grads", self.world), shard)
@@ -173,18 +209,22 @@ class Backup(_LogStrategy):
         super().__init__(comm, board)
         self.m = min(max(1, replicas_to_aggregate), comm.world)
 
-    def step(self, replica, step: int, lr: LrLike) -> StepResult:
+    def compute_gradients(self, replica, lr: LrLike = 0.0) -> PendingGradients:
+        if self._plain():
+            return self._plain_compute(replica)
         t0 = time.time()
-        if self.world == 1 or self.board is None:
-            return self._plain_step(replica, lr, t0)
-        log = self._get_log(replica)
-        done = log.forward_backward(replica)
-        dt = time.time() - t0
-        if done:
+        done = self._get_log(replica).forward_backward(replica)
+        return PendingGradients(replica, t0, done, time.time() - t0)
+
+    def apply_gradients(self, pending: PendingGradients, lr: LrLike) -> StepResult:
+        if self._plain():
+            return self._plain_apply(pending, lr)
+        log = self._get_log(pending.replica)
+        if pending.done:
             res = log.contribute(lr, quorum=self.m, abort_at=self.m)
         else:
             res = log.skip(lr)   # the update closed while this replica was still back-propagating
-        return self._result(res, done, self.m, dt)
+        return self._result(res, pending.done, self.m, pending.compute_s)
 
 
 class Interval(_LogStrategy):
@@ -227,17 +267,25 @@ class Interval(_LogStrategy):
             self._timer.join(timeout=30)
             self._timer = None
 
-    def step(self, replica, step: int, lr: LrLike) -> StepResult:
+    def _plain(self) -> bool:
+        return self.board is None      # one replica with a board still runs on its timer
+
+    def compute_gradients(self, replica, lr: LrLike = 0.0) -> PendingGradients:
+        if self._plain():
+            return self._plain_compute(replica)
         t0 = time.time()
-        if self.world == 1 and self.board is None:
-            return self._plain_step(replica, lr, t0)
         log = self._get_log(replica)
         self.start_interval_updates(replica)
         log.catch_up(lr, reduce_own=False)      # start from the newest parameters, like a worker reading the parameter server
         done = log.forward_backward(replica, abortable=False)
-        dt = time.time() - t0
+        return PendingGradients(replica, t0, done, time.time() - t0)
+
+    def apply_gradients(self, pending: PendingGradients, lr: LrLike) -> StepResult:
+        if self._plain():
+            return self._plain_apply(pending, lr)
+        log = self._get_log(pending.replica)
         res = log.contribute_open(lr, self.max_staleness)
-        return self._result(res, done, log.contributors_hint(), dt)
+        return self._result(res, pending.done, log.contributors_hint(), pending.compute_s)
 
     def finish(self) -> None:
         if self.log is not None:
@@ -254,16 +302,20 @@ class SoftKill(_LogStrategy):
         super().__init__(comm, board)
         self.k = should_stop_worker_num
 
-    def step(self, replica, step: int, lr: LrLike) -> StepResult:
+    def compute_gradients(self, replica, lr: LrLike = 0.0) -> PendingGradients:
+        if self._plain():
+            return self._plain_compute(replica)
         t0 = time.time()
-        if self.world == 1 or self.board is None:
-            return self._plain_step(replica, lr, t0)
-        log = self._get_log(replica)
-        done = log.forward_backward(replica)
-        dt = time.time() - t0
+        done = self._get_log(replica).forward_backward(replica)
+        return PendingGradients(replica, t0, done, time.time() - t0)
+
+    def apply_gradients(self, pending: PendingGradients, lr: LrLike) -> StepResult:
+        if self._plain():
+            return self._plain_apply(pending, lr)
+        log = self._get_log(pending.replica)
         # a short-circuited replica still pushes what it has (zeros for the layers it did not reach)
         res = log.contribute(lr, quorum=self.world, abort_at=self.k, scale=1.0 / self.world)
-        return self._result(res, done, self.world, dt)
+        return self._result(res, pending.done, self.world, pending.compute_s)
 
 
 def ls_gradient_weights(num_workers: int, num_batches: int, killed: List[int]) -> np.ndarray:
@@ -295,23 +347,28 @@ class Weighted(_LogStrategy):
         killed = list(rng.choice(self.world, size=self.num_kill, replace=False)) if self.num_kill else []
         return ls_gradient_weights(self.world, self.world, killed)
 
-    def step(self, replica, step: int, lr: LrLike) -> StepResult:
+    def compute_gradients(self, replica, lr: LrLike = 0.0) -> PendingGradients:
+        if self._plain():
+            return self._plain_compute(replica)
         t0 = time.time()
-        if self.world == 1 or self.board is None:
-            return self._plain_step(replica, lr, t0)
         log = self._get_log(replica)
         # the kill draw belongs to the UPDATE (identical on every replica whatever its iteration count)
         w = self.weights_for_step(log.sync_version())
         wr = float(w[self.rank])
-        alive = int((w != 0).sum())
-        total = float(w.sum())
-        if wr == 0.0:
-            res = log.skip(lr)                   # a killed worker does no work for this update
-            return self._result(res, True, alive, time.time() - t0)
-        log.forward_backward(replica, abortable=False)
-        dt = time.time() - t0
-        res = log.contribute(lr, weight=wr, quorum=alive, scale=1.0 / total if total > 0 else 0.0)
-        return self._result(res, True, alive, dt)
+        if wr != 0.0:                            # a killed worker does no work for this update
+            log.forward_backward(replica, abortable=False)
+        return PendingGradients(replica, t0, True, time.time() - t0, weight=wr, alive=int((w != 0).sum()), total_weight=float(w.sum()))
+
+    def apply_gradients(self, pending: PendingGradients, lr: LrLike) -> StepResult:
+        if self._plain():
+            return self._plain_apply(pending, lr)
+        log = self._get_log(pending.replica)
+        if pending.weight == 0.0:
+            res = log.skip(lr)
+        else:
+            total = pending.total_weight
+            res = log.contribute(lr, weight=pending.weight, quorum=pending.alive, scale=1.0 / total if total > 0 else 0.0)
+        return self._result(res, True, pending.alive, pending.compute_s)
 
 
 def make_strategy(flags, comm: Communicator, board, replicas_to_aggregate: int) -> Strategy:

@@ -91,6 +91,36 @@ def test_reference_named_wrappers_single_replica(make):
     assert not torch.equal(before, rep.arena.params)
 
 
+def test_two_phase_api_matches_one_call_step():
+    """compute_gradients + apply_gradients(grads, worker_id, global_step) is the same step as .step()."""
+    comm = Communicator.single("cpu")
+    rng = np.random.RandomState(0)
+    x = rng.rand(8, 28, 28, 1).astype(np.float32) - 0.5
+    y = rng.randint(0, 10, size=8)
+    reps = [make_replica("lenet", 8, device="cpu") for _ in range(2)]
+    for r in reps:
+        r.load_batch(x, y)
+    one = BackupOptimizer("adam", 1, comm=comm)
+    one.step(reps[0], 0, 1e-3)
+    two = BackupOptimizer("adam", 1, comm=comm)
+    runner = two.get_chief_queue_runner().start()
+    two.get_init_tokens_op()()
+    two.chief_init_op(), two.local_step_init_op()
+    assert two.ready_for_local_init_op()
+    grads = two.compute_gradients(reps[1])
+    assert float(reps[1].arena.grads.abs().sum()) > 0          # the gradient is there before anything is applied
+    res = two.apply_gradients(grads, worker_id=0, global_step=0, lr=1e-3)
+    assert res.applied and res.global_step == 1
+    assert torch.equal(reps[0].arena.params, reps[1].arena.params)
+    with pytest.raises(ValueError):
+        two.apply_gradients(two.compute_gradients(reps[1]), worker_id=3, global_step=1, lr=1e-3)
+    runner.stop()
+    hook = WeightedGradsOptimizer("adam", comm=comm, num_worker_kill=0).make_session_run_hook(True)
+    hook.begin()
+    hook.after_create_session()
+    assert hook.runner.started
+
+
 def test_wrapper_rejects_wrong_replica_count():
     with pytest.raises(ValueError):
         BackupOptimizer("adam", 2, total_num_replicas=4, comm=Communicator.single("cpu"))

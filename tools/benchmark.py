@@ -177,8 +177,9 @@ def plot_time_loss(results: Dict[str, Dict], outdir: str) -> None:
         plt.figure()
         for name, r in results.items():
             if r["eval_times"]:
-                t = np.cumsum(r["eval_times"]) if False else np.arange(len(r[key]))
-                plt.plot(r["eval_wall"][: len(r[key])] if r.get("eval_wall") else t, r[key], label=name)
+                # wall-clock of each evaluation when the log carries it, else the evaluation's index
+                t = r["eval_wall"][: len(r[key])] if r.get("eval_wall") else np.arange(len(r[key]))
+                plt.plot(t, r[key], label=name)
         plt.xlabel("Time (s)")
         plt.ylabel(ylabel)
         plt.legend(fontsize=6)
