@@ -421,6 +421,22 @@ PYBIND11_MODULE(_hip, m) {
         current_recorder() = nullptr;
       })
       .def("mark_segment", &Program::mark_segment)
+      .def("mark_phase", &Program::mark_phase)
+      .def("phase_names", [](const Program& p) {
+        std::vector<std::string> v;
+        for (auto& ph : p.phases) v.push_back(ph.second);
+        return v;
+      })
+      .def("run_traced", [](const Program& p, uint64_t stream, int seg, uint64_t base_event) {
+        std::vector<Program::TraceEvent> evs;
+        {
+          py::gil_scoped_release rel;
+          evs = p.run_traced(as_stream(stream), seg, reinterpret_cast<hipEvent_t>(base_event));
+        }
+        py::list out;
+        for (auto& e : evs) out.append(py::make_tuple(e.name, e.lane, e.phase, e.ts_us, e.dur_us, e.blocks, e.threads));
+        return out;
+      }, py::arg("stream"), py::arg("seg") = -1, py::arg("base_event") = 0)
       .def("set_lane", &Program::set_lane)
       .def("sync_lanes", &Program::sync_lanes)
       .def_property_readonly("num_segments", &Program::num_segments)

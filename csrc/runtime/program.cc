@@ -128,6 +128,74 @@ void Program::run(hipStream_t stream, int seg) const {
   }
 }
 
+std::vector<Program::TraceEvent> Program::run_traced(hipStream_t stream, int seg, hipEvent_t base) const {
+  size_t b = 0, e = records.size();
+  if (seg >= 0) {
+    if ((size_t)seg >= seg_begin.size()) throw std::runtime_error("Program::run_traced: bad segment");
+    b = seg_begin[seg];
+    e = ((size_t)seg + 1 < seg_begin.size()) ? seg_begin[seg + 1] : records.size();
+  }
+  struct Pair {
+    size_t rec;
+    hipEvent_t t0, t1;
+  };
+  std::vector<Pair> pairs;
+  pairs.reserve(e - b);
+  auto cleanup = [&pairs]() {
+    for (auto& p : pairs) {
+      if (p.t0) (void)hipEventDestroy(p.t0);
+      if (p.t1) (void)hipEventDestroy(p.t1);
+    }
+  };
+  std::vector<TraceEvent> out;
+  try {
+    for (size_t i = b; i < e; ++i) {
+      const LaunchRecord& r = records[i];
+      if (r.kind == LaunchRecord::SYNC) {
+        hipEvent_t& ev = events_[r.event];
+        if (!ev) DTF_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        DTF_HIP_CHECK(hipEventRecord(ev, lane_stream(stream, r.src_lane)));
+        DTF_HIP_CHECK(hipStreamWaitEvent(lane_stream(stream, r.lane), ev, 0));
+        continue;
+      }
+      hipStream_t s = lane_stream(stream, r.lane);
+      Pair p{i, nullptr, nullptr};
+      DTF_HIP_CHECK(hipEventCreate(&p.t0));
+      pairs.push_back(p);
+      DTF_HIP_CHECK(hipEventCreate(&pairs.back().t1));
+      DTF_HIP_CHECK(hipEventRecord(pairs.back().t0, s));
+      issue(r, s);
+      DTF_HIP_CHECK(hipEventRecord(pairs.back().t1, s));
+    }
+    // side lanes are joined by the program's own SYNC records; waiting for each end event covers all
+    for (auto& p : pairs) DTF_HIP_CHECK(hipEventSynchronize(p.t1));
+    hipEvent_t origin = base ? base : (pairs.empty() ? nullptr : pairs.front().t0);
+    for (auto& p : pairs) {
+      const LaunchRecord& r = records[p.rec];
+      float ts = 0.f, dur = 0.f;
+      DTF_HIP_CHECK(hipEventElapsedTime(&ts, origin, p.t0));
+      DTF_HIP_CHECK(hipEventElapsedTime(&dur, p.t0, p.t1));
+      int phase = -1;
+      for (size_t k = 0; k < phases.size(); ++k)
+        if (phases[k].first <= p.rec) phase = (int)k;
+      TraceEvent ev;
+      ev.name = r.name;
+      ev.lane = r.lane;
+      ev.phase = phase;
+      ev.ts_us = (double)ts * 1e3;
+      ev.dur_us = (double)dur * 1e3;
+      ev.blocks = r.kind == LaunchRecord::KERNEL ? r.grid.x * r.grid.y * r.grid.z : 0;
+      ev.threads = r.kind == LaunchRecord::KERNEL ? r.block.x * r.block.y * r.block.z : 0;
+      out.push_back(std::move(ev));
+    }
+  } catch (...) {
+    cleanup();
+    throw;
+  }
+  cleanup();
+  return out;
+}
+
 void Program::instantiate(hipStream_t stream, int seg) {
   size_t slot = (size_t)(seg + 1);
   if (graphs_.size() <= slot) graphs_.resize(slot + 1);

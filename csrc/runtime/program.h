@@ -75,6 +75,25 @@ class Program {
   std::vector<size_t> seg_begin{0};
 
   void mark_segment() { seg_begin.push_back(records.size()); }
+  // Phases ("forward", "backward", "optimizer", ...) for the step timeline: a phase covers the records
+  // from this call to the next mark_phase (or the end). They do not affect execution.
+  std::vector<std::pair<size_t, std::string>> phases;
+  void mark_phase(const std::string& name) { phases.emplace_back(records.size(), name); }
+  // One timed launch of a traced run. ts/dur in microseconds; ts is relative to `base` (or to the
+  // first launch of the run when base is null). phase = index into `phases`, -1 before the first mark.
+  struct TraceEvent {
+    std::string name;
+    int lane;
+    int phase;
+    double ts_us, dur_us;
+    unsigned blocks, threads;
+  };
+  // Issues the launches of one segment (or all) like run(), each bracketed by a pair of timing
+  // events on its lane's stream, waits for them and returns one event per launch: the per-op step
+  // timeline (reference: RunOptions.FULL_TRACE + timeline.Timeline,
+  // DistributedLeNet/src/distributed_train.py:300-305,324-328). Slower than run() - the launches are
+  // not graph-replayed and the call blocks - so it is for the steps that are being traced only.
+  std::vector<TraceEvent> run_traced(hipStream_t stream, int seg, hipEvent_t base) const;
   // Lane that subsequently recorded launches go to (recording thread only).
   void set_lane(int lane);
   int lane() const { return lane_; }

@@ -64,7 +64,9 @@ class LeNetHipStep(StepProgramBase):
         B = self.batch
         p.begin_record()
         try:
+            p.mark_phase("prologue")
             self._record_prologue()
+            p.mark_phase("forward")
             nv.conv5x5_pack(a.param("conv2_weights"), self.wpk2)
             # ---------------- forward
             # conv1 + bias + ReLU + pool in one kernel: the 28x28x32 activation is never written
@@ -84,6 +86,7 @@ class LeNetHipStep(StepProgramBase):
                 # ---------------- backward
                 # the arena's gradients were zeroed by the step prologue: accumulating into them
                 # spares the split-K products their own clearing pass
+                p.mark_phase("backward")
                 nv.gemm(hd, self.dlogits, trans_a=True, out=a.grad("fc2_weights"), accumulate=True)
                 nv.col_sum(self.dlogits, a.grad("fc2_biases"))
                 nv.gemm(self.dlogits, a.param("fc2_weights"), trans_b=True, out=self.dh)
@@ -128,6 +131,7 @@ class LeNetHipStep(StepProgramBase):
                 nv.slot_reduce(a.grads, self._wslots, 0, conv_end)
                 self.bucket_ranges.append((0, lo))
                 p.mark_segment()
+                p.mark_phase("optimizer")
                 self._record_optimizer()
         finally:
             p.end_record()

@@ -389,10 +389,14 @@ class ResNetHipStep(StepProgramBase):
         p = self.program
         p.begin_record()
         try:
+            p.mark_phase("prologue")
             self._record_prologue([self.stats, self._tile_ctr] if self.training and self.dynamic_tiles else [self.stats])
+            p.mark_phase("forward")
             self._record_forward()
             if self.training:
+                p.mark_phase("backward")
                 self._record_backward(num_buckets)
+                p.mark_phase("optimizer")
                 self._record_optimizer()
         finally:
             p.end_record()

@@ -117,14 +117,17 @@ class Strategy:
     def _plain_compute(self, replica) -> PendingGradients:
         """Forward + backward with the bucketed all-reduce overlapped."""
         t0 = time.time()
-        replica.forward_backward(on_bucket=self._bucket_reduce(replica))
+        with replica.span("forward+backward (gradient all-reduce overlapped)" if self.world > 1 else "forward+backward"):
+            replica.forward_backward(on_bucket=self._bucket_reduce(replica))
         return PendingGradients(replica, t0, True, time.time() - t0)
 
     def _plain_apply(self, pending: PendingGradients, lr: LrLike) -> StepResult:
         replica = pending.replica
-        with replica.stream_ctx():
-            self.comm.wait_all()
-        replica.apply_update(lr_at(lr, replica.updates_applied), grad_scale=1.0 / self.world)
+        if self.world > 1:
+            with replica.span("gradient all-reduce (tail)"), replica.stream_ctx():
+                self.comm.wait_all()
+        with replica.span("optimizer"):
+            replica.apply_update(lr_at(lr, replica.updates_applied), grad_scale=1.0 / self.world)
         return StepResult(True, self.world, False, True, pending.compute_s, replica.updates_applied)
 
     def _bucket_reduce(self, replica):
@@ -151,7 +154,8 @@ class FullSync(Strategy):
     def compute_gradients(self, replica, lr: LrLike = 0.0) -> PendingGradients:
         if self.reduce_scatter and self.world > 1:
             t0 = time.time()
-            replica.forward_backward()
+            with replica.span("forward+backward"):
+                replica.forward_backward()
             return PendingGradients(replica, t0, True, time.time() - t0)
         return self._plain_compute(replica)
 
@@ -170,10 +174,11 @@ class FullSync(Strategy):
         a = replica.arena
         shard = a.shard_size(self.world)
         lo, hi = self.rank * shard, (self.rank + 1) * shard
-        with replica.stream_ctx():
+        with replica.span("gradient reduce-scatter"), replica.stream_ctx():
             self.comm.reduce_scatter_flat(a.padded("grads", self.world), shard)
-        replica.apply_update_shard(lr, 1.0 / self.world, lo, hi)
-        with replica.stream_ctx():
+        with replica.span("optimizer (own shard)"):
+            replica.apply_update_shard(lr, 1.0 / self.world, lo, hi)
+        with replica.span("parameter all-gather"), replica.stream_ctx():
             self.comm.all_gather_flat(a.padded("params", self.world), shard)
         return StepResult(True, self.world, False, True, dt, replica.updates_applied)
 
@@ -213,17 +218,19 @@ class Backup(_LogStrategy):
         if self._plain():
             return self._plain_compute(replica)
         t0 = time.time()
-        done = self._get_log(replica).forward_backward(replica)
+        with replica.span("forward+backward (short-circuits when the update completes)"):
+            done = self._get_log(replica).forward_backward(replica)
         return PendingGradients(replica, t0, done, time.time() - t0)
 
     def apply_gradients(self, pending: PendingGradients, lr: LrLike) -> StepResult:
         if self._plain():
             return self._plain_apply(pending, lr)
         log = self._get_log(pending.replica)
-        if pending.done:
-            res = log.contribute(lr, quorum=self.m, abort_at=self.m)
-        else:
-            res = log.skip(lr)   # the update closed while this replica was still back-propagating
+        with pending.replica.span("update log: arrive, reduce, gather + optimizer"):
+            if pending.done:
+                res = log.contribute(lr, quorum=self.m, abort_at=self.m)
+            else:
+                res = log.skip(lr)   # the update closed while this replica was still back-propagating
         return self._result(res, pending.done, self.m, pending.compute_s)
 
 
@@ -276,15 +283,18 @@ class Interval(_LogStrategy):
         t0 = time.time()
         log = self._get_log(replica)
         self.start_interval_updates(replica)
-        log.catch_up(lr, reduce_own=False)      # start from the newest parameters, like a worker reading the parameter server
-        done = log.forward_backward(replica, abortable=False)
+        with replica.span("update log: apply closed windows"):
+            log.catch_up(lr, reduce_own=False)  # start from the newest parameters, like a worker reading the parameter server
+        with replica.span("forward+backward"):
+            done = log.forward_backward(replica, abortable=False)
         return PendingGradients(replica, t0, done, time.time() - t0)
 
     def apply_gradients(self, pending: PendingGradients, lr: LrLike) -> StepResult:
         if self._plain():
             return self._plain_apply(pending, lr)
         log = self._get_log(pending.replica)
-        res = log.contribute_open(lr, self.max_staleness)
+        with pending.replica.span("update log: push into the open window"):
+            res = log.contribute_open(lr, self.max_staleness)
         return self._result(res, pending.done, log.contributors_hint(), pending.compute_s)
 
     def finish(self) -> None:
@@ -306,7 +316,8 @@ class SoftKill(_LogStrategy):
         if self._plain():
             return self._plain_compute(replica)
         t0 = time.time()
-        done = self._get_log(replica).forward_backward(replica)
+        with replica.span("forward+backward (short-circuits when the update completes)"):
+            done = self._get_log(replica).forward_backward(replica)
         return PendingGradients(replica, t0, done, time.time() - t0)
 
     def apply_gradients(self, pending: PendingGradients, lr: LrLike) -> StepResult:
@@ -314,7 +325,8 @@ class SoftKill(_LogStrategy):
             return self._plain_apply(pending, lr)
         log = self._get_log(pending.replica)
         # a short-circuited replica still pushes what it has (zeros for the layers it did not reach)
-        res = log.contribute(lr, quorum=self.world, abort_at=self.k, scale=1.0 / self.world)
+        with pending.replica.span("update log: arrive, reduce, gather + optimizer"):
+            res = log.contribute(lr, quorum=self.world, abort_at=self.k, scale=1.0 / self.world)
         return self._result(res, pending.done, self.world, pending.compute_s)
 
 

@@ -90,6 +90,15 @@ class StepProgramBase:
         else:
             self.program.run(s, seg)
 
+    def run_traced(self, seg: int = -1, base_event: int = 0):
+        """Runs the whole step (seg < 0) or one segment launch by launch, each bracketed by timing
+        events, and returns [(kernel name, lane, phase name, start us, duration us, blocks, threads)];
+        start is relative to `base_event` (a raw hipEvent handle recorded earlier on this stream)."""
+        s = torch.cuda.current_stream().cuda_stream
+        phases = self.program.phase_names()
+        return [(n, lane, phases[ph] if ph >= 0 else "", ts, dur, blocks, threads)
+                for n, lane, ph, ts, dur, blocks, threads in self.program.run_traced(s, seg, base_event)]
+
     def zero_grad_range(self, lo: int, hi: int) -> None:
         """Zeroes grads[lo:hi] on the current stream (short-circuited backward)."""
         if hi > lo:

@@ -226,6 +226,8 @@ def train(flags, model: str) -> Dict:
 
     timeout_client, timeout_server = control_plane.launch_manager(board, rank, world, flags.collective_timeout_s)
     timeline = StepTimeline(rank, enabled=flags.timeline_logging)
+    if flags.timeline_logging:
+        replica.timeline = timeline        # traced steps: one event per kernel, phase spans from the policy
     summary_writer = None
     if is_chief and flags.should_summarize:
         from ..utils.summary import FileWriter
@@ -261,7 +263,7 @@ def train(flags, model: str) -> Dict:
             images, labels = feed.next()
             replica.load_batch(images, labels)
         _inject_straggler(flags, rank, rng)
-        timeline.reset()
+        timeline.reset(getattr(replica, "stream", None))
         log.info("RUNNING SESSION... %f" % time.time())
         if async_mode:
             with timeline.span("async_step"):

@@ -39,6 +39,14 @@ class ReplicaBase:
     optimizer: str
     updates_applied: int = 0
     last_aborted: bool = False
+    timeline = None            # a train.timeline.StepTimeline while steps are being traced
+
+    def span(self, name: str):
+        """Timeline span around a phase of the step (no-op unless a timeline is attached)."""
+        tl = self.timeline
+        if tl is None or not tl.enabled:
+            return contextlib.nullcontext()
+        return tl.span(name, getattr(self, "stream", None))
 
     def adam_lr_t(self, lr: float) -> float:
         return ref.adam_lr_t(lr, self.updates_applied + 1)
@@ -237,7 +245,7 @@ class HipReplica(ReplicaBase):
         with torch.cuda.stream(self.stream):
             st.set_step_counter(self.updates_applied)
             for i in range(nseg - 1):
-                st.run(i, self.use_graph)
+                self._run_segment(i)
                 lo, hi = st.bucket_ranges[i]
                 if should_abort is not None and i < nseg - 2:
                     # The host runs ahead of the GPU: wait for the segment before polling, so
@@ -258,12 +266,20 @@ class HipReplica(ReplicaBase):
                     on_bucket(lo, hi)
         return True
 
+    def _run_segment(self, seg: int) -> None:
+        """Replays one segment; while a timeline is attached, launch by launch with per-kernel events."""
+        tl = self.timeline
+        if tl is not None and tl.enabled:
+            tl.add_kernel_events(self.step.run_traced(seg, tl.base_event_handle))
+        else:
+            self.step.run(seg, self.use_graph)
+
     def apply_update(self, lr: float, grad_scale: float = 1.0) -> None:
         st = self.step
         with torch.cuda.stream(self.stream):
             lr_t = self.adam_lr_t(lr) if self.optimizer == "adam" else lr
             st.set_hyper(lr_t=lr_t, grad_scale=grad_scale, momentum=self.momentum, weight_decay=self.weight_decay)
-            st.run(st.num_segments - 1, self.use_graph)
+            self._run_segment(st.num_segments - 1)
         self.updates_applied += 1
 
     def apply_update_shard(self, lr: float, grad_scale: float, lo: int, hi: int) -> None:

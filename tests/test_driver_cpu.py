@@ -204,3 +204,24 @@ def test_benchmark_parsers_on_reference_shaped_logs(tmp_path):
     benchmark.plot_time_loss(res, str(tmp_path))
     benchmark.plot_time_cdfs(res, str(tmp_path))
     assert os.path.exists(tmp_path / "time_loss.png") and os.path.exists(tmp_path / "step_losses.png") and os.path.exists(tmp_path / "time_cdfs.png")
+
+
+def test_timeline_json_carries_kernel_events_and_phase_spans(tmp_path):
+    import json
+
+    from distributed_tensorflow_amd.train.timeline import StepTimeline
+
+    tl = StepTimeline(3, enabled=True, use_cuda=False)
+    tl.reset()
+    with tl.span("train_step"):
+        tl.add_kernel_events([("zero_multi", 0, "prologue", 0.0, 2.0, 8, 256), ("conv_fprop_band", 0, "forward", 3.0, 40.0, 256, 256),
+                              ("conv_wgrad_band", 1, "backward", 50.0, 30.0, 512, 256), ("adam", 0, "optimizer", 90.0, 5.0, 64, 256)])
+    path = tl.write(str(tmp_path), 7)
+    assert path.endswith("worker=3_timeline_iter=7.json")
+    ev = json.load(open(path))["traceEvents"]
+    kernels = [e for e in ev if e.get("cat") == "kernel"]
+    assert [k["name"] for k in kernels] == ["zero_multi", "conv_fprop_band", "conv_wgrad_band", "adam"]
+    assert kernels[2]["tid"] == 2 and kernels[2]["args"] == {"phase": "backward", "blocks": 512, "threads_per_block": 256}
+    phases = {e["name"]: (e["ts"], e["dur"]) for e in ev if e.get("cat") == "phase"}
+    assert phases["forward"] == (3.0, 40.0) and phases["backward"] == (50.0, 30.0)
+    assert any(e.get("cat") == "host" and e["name"] == "train_step" for e in ev)

@@ -284,3 +284,49 @@ def test_set_scalars_values_travel_with_the_launch():
     torch.cuda.synchronize()
     for k, (fo, uo) in enumerate(outs):
         assert fo[:3].tolist() == [float(k), float(2 * k), 0.5] and int(uo[0]) == k << 20
+
+
+def test_traced_step_timeline_has_one_event_per_kernel_and_the_phases(tmp_path):
+    """A traced ResNet-20 step: every launch of the step program shows up as a named event with a
+    duration, on the same time axis as the phase spans (the per-op chrome trace of the reference's
+    --timeline_logging, DistributedLeNet/src/distributed_train.py:300-328)."""
+    import json
+
+    from distributed_tensorflow_amd.parallel.comm import Communicator
+    from distributed_tensorflow_amd.parallel.strategies import FullSync
+    from distributed_tensorflow_amd.train.replica import HipReplica
+    from distributed_tensorflow_amd.train.timeline import StepTimeline
+
+    rep = HipReplica("resnet", 64, num_residual_blocks=3)
+    g = torch.Generator().manual_seed(3)
+    rep.load_batch(torch.randn(64, 32, 32, 3, generator=g), torch.randint(0, 10, (64,), generator=g))
+    strat = FullSync(Communicator.single("cuda"))
+    strat.step(rep, 0, 1e-3)                       # an ordinary (graph-replayed) step first
+    rep.synchronize()
+    before = rep.arena.params.clone()
+    tl = StepTimeline(0, enabled=True)
+    rep.timeline = tl
+    tl.reset(rep.stream)
+    with tl.span("train_step", rep.stream):
+        strat.step(rep, 1, 1e-3)
+    rep.synchronize()
+    assert not torch.equal(before, rep.arena.params)          # the traced step is a real step
+    path = tl.write(str(tmp_path), 1)
+    events = json.load(open(path))["traceEvents"]
+    kernels = [e for e in events if e.get("cat") == "kernel"]
+    assert len(kernels) == rep.step.kernel_count >= 50
+    assert all(e["dur"] > 0 and e["ts"] >= 0 and e["args"]["blocks"] >= 0 for e in kernels)
+    names = {e["name"] for e in kernels}
+    assert any("conv" in n for n in names) and any("adam" in n for n in names), names
+    phases = {e["name"]: e for e in events if e.get("cat") == "phase"}
+    assert {"prologue", "forward", "backward", "optimizer"} <= set(phases)
+    assert phases["forward"]["ts"] < phases["backward"]["ts"] < phases["optimizer"]["ts"]
+    spans = {e["name"] for e in events if e.get("cat") == "gpu"}
+    assert {"train_step", "forward+backward", "optimizer"} <= spans
+    # kernels lie inside the step's GPU span
+    step = next(e for e in events if e.get("cat") == "gpu" and e["name"] == "train_step")
+    assert all(step["ts"] - 50 <= e["ts"] and e["ts"] + e["dur"] <= step["ts"] + step["dur"] + 50 for e in kernels)
+    # back to graph replay afterwards
+    rep.timeline = None
+    strat.step(rep, 2, 1e-3)
+    rep.synchronize()
