@@ -124,6 +124,8 @@ PYBIND11_MODULE(_host, m) {
       .def("local_step", &Board::local_step)
       .def("heartbeat", &Board::heartbeat)
       .def("last_heartbeat_ns", &Board::last_heartbeat_ns)
+      .def("depart", &Board::depart)
+      .def_property_readonly_static("DEPARTED", [](py::object) { return Board::kDeparted; })
       .def("shard_version", &Board::shard_version)
       .def("bump_shard_version", &Board::bump_shard_version)
       .def("ring_doorbell", &Board::ring_doorbell)

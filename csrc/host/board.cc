@@ -234,6 +234,7 @@ int64_t Board::local_step(int rank) const { return lay_->local_step[rank].load(s
 // ---- heartbeats ---------------------------------------------------------------------------------------
 void Board::heartbeat(int rank) { lay_->heartbeat_ns[rank].store(now_ns(), std::memory_order_release); }
 int64_t Board::last_heartbeat_ns(int rank) const { return lay_->heartbeat_ns[rank].load(std::memory_order_acquire); }
+void Board::depart(int rank) { lay_->heartbeat_ns[rank].store(kDeparted, std::memory_order_release); }
 
 // ---- async shards -------------------------------------------------------------------------------------
 int64_t Board::shard_version(int owner) const { return lay_->shard_version[owner].load(std::memory_order_acquire); }

@@ -136,9 +136,12 @@ class Board {
   void set_local_step(int rank, int64_t s);
   int64_t local_step(int rank) const;
 
-  // ---- heartbeats
+  // ---- heartbeats: wall-clock ns of the replica's last sign of life; 0 = not started yet,
+  // kDeparted = it finished its work and left on purpose (never to be taken for dead)
+  static constexpr int64_t kDeparted = INT64_MAX;
   void heartbeat(int rank);
   int64_t last_heartbeat_ns(int rank) const;
+  void depart(int rank);
 
   // ---- async parameter shards
   int64_t shard_version(int owner) const;

@@ -16,8 +16,10 @@ from __future__ import annotations
 
 import logging
 import os
+import sys
+import threading
 import time
-from typing import Dict, List, Optional, Tuple
+from typing import Callable, Dict, List, Optional, Set, Tuple
 
 log = logging.getLogger("dtf")
 
@@ -142,3 +144,89 @@ def launch_manager(board, worker_id: int, n_workers: int, timeout_s: float = 600
             raise TimeoutError(f"worker {worker_id}: not all {n_workers} workers became ready within {timeout_s}s")
     log.info("Server ready to start!")
     return client, server
+
+
+class Watchdog(threading.Thread):
+    """Liveness of the workers of one job.
+
+    The reference's side channel keeps a reconnecting client per worker with a 30 s protocol
+    timeout (reference: DistributedLeNet/src/timeout_manager.py:79-105,120-130): a worker that
+    goes away is noticed by the others. Here every worker runs this thread: it stamps the worker's
+    own heartbeat on the board (so the stamp says "the process is alive", whatever its training
+    thread is blocked in) and reads everybody else's. A worker whose stamp is older than
+    `silence_s` is declared dead, by name, once:
+
+      * `tolerate(dead)` true - the policy can go on without it (backup workers with enough
+        replicas left, timer-driven updates while the chief lives): the worker is marked dead on
+        the board, which takes it out of the update log's back-pressure, and `on_dead(rank)` runs;
+      * otherwise the job cannot make progress (a collective would wait for the dead worker until
+        the process group's own timeout): the stop flag is raised for everybody and this process
+        ends at once with `exit_code` - from the thread, because the training thread may be stuck
+        inside a collective. Nothing is re-executed in a process that holds a GPU; the launcher
+        sees the non-zero status.
+
+    A worker that finishes normally calls `depart()`, which marks it as gone on purpose.
+    """
+
+    def __init__(self, board, rank: int, world: int, silence_s: float, tolerate: Optional[Callable[[Set[int]], bool]] = None,
+                 on_dead: Optional[Callable[[int], None]] = None, exit_code: int = 3, period_s: Optional[float] = None):
+        super().__init__(name="liveness-watchdog", daemon=True)
+        self.board, self.rank, self.world = board, rank, world
+        self.silence_s = float(silence_s)
+        self.period_s = period_s if period_s is not None else max(0.05, min(1.0, self.silence_s / 8))
+        self.tolerate = tolerate or (lambda dead: False)
+        self.on_dead = on_dead
+        self.exit_code = exit_code
+        self.dead: Set[int] = set()
+        self._stop_evt = threading.Event()
+        self._t_start_ns = 0
+
+    def run(self) -> None:
+        b = self.board
+        self._t_start_ns = b.now_ns()
+        while not self._stop_evt.wait(self.period_s):
+            b.heartbeat(self.rank)
+            if b.should_stop():
+                return
+            now = b.now_ns()
+            for r in range(self.world):
+                if r == self.rank or r in self.dead:
+                    continue
+                last = b.last_heartbeat_ns(r)
+                if last == type(b).DEPARTED:
+                    continue
+                silent_s = (now - max(last, self._t_start_ns)) / 1e9
+                if silent_s > self.silence_s:
+                    self._declare_dead(r, silent_s)
+
+    def _declare_dead(self, r: int, silent_s: float) -> None:
+        self.dead.add(r)
+        b = self.board
+        b.agg_mark_dead(r)
+        if self.tolerate(set(self.dead)):
+            log.error("Worker %d: worker %d has been silent for %.1f s and is taken for dead; continuing without it",
+                      self.rank, r, silent_s)
+            if self.on_dead is not None:
+                try:
+                    self.on_dead(r)
+                except Exception as e:   # noqa: BLE001 - the watchdog must keep running
+                    log.error("Worker %d: on_dead(%d) failed: %s", self.rank, r, e)
+            return
+        log.error("Worker %d: worker %d has been silent for %.1f s and is taken for dead; the job cannot continue, stopping",
+                  self.rank, r, silent_s)
+        b.request_stop()
+        for h in log.handlers + logging.getLogger().handlers:
+            try:
+                h.flush()
+            except Exception:   # noqa: BLE001
+                pass
+        sys.stderr.flush()
+        os._exit(self.exit_code)
+
+    def beat(self) -> None:
+        self.board.heartbeat(self.rank)
+
+    def depart(self) -> None:
+        """This worker is done: stop watching and tell the others it left on purpose."""
+        self._stop_evt.set()
+        self.board.depart(self.rank)

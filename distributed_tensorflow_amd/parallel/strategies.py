@@ -93,13 +93,15 @@ class Strategy:
     def apply_gradients(self, pending: PendingGradients, lr: LrLike) -> StepResult:  # pragma: no cover - interface
         raise NotImplementedError
 
-    def finish(self) -> None:
+    def finish(self, collective: bool = True) -> None:
         """End of training (all replicas call it): keeps published data reachable until every
-        live replica has caught up, then releases it."""
+        live replica has caught up, then releases it. collective=False: a worker died, so nothing
+        here may wait for all ranks; the survivors agree through the board alone."""
         if self.log is not None:
-            self.log.finish()
-            self.comm.barrier()
-            self.log.close()
+            self.log.finish(collective=collective) if not collective else self.log.finish()
+            if collective:
+                self.comm.barrier()
+                self.log.close()
             self.log = None
 
     # helpers --------------------------------------------------------------------------------------
@@ -297,12 +299,14 @@ class Interval(_LogStrategy):
             res = log.contribute_open(lr, self.max_staleness)
         return self._result(res, pending.done, log.contributors_hint(), pending.compute_s)
 
-    def finish(self) -> None:
-        if self.log is not None:
+    def finish(self, collective: bool = True) -> None:
+        if self.log is not None and collective:
             self.comm.barrier()            # nobody pushes any more
             self.stop_interval_updates()   # chief: no window closes after this
             self.comm.barrier()
-        super().finish()
+        else:
+            self.stop_interval_updates()
+        super().finish(collective)
 
 
 class SoftKill(_LogStrategy):

@@ -277,7 +277,7 @@ class HostUpdateLog:
             b.agg_set_applied(self.rank, self.version)
             n += 1
 
-    def finish(self, final_version: Optional[int] = None) -> None:
+    def finish(self, final_version: Optional[int] = None, collective: bool = True) -> None:
         """End of training: a replica may stop contributing while others still need its published
         shards; keep the mappings until every live replica has applied everything closed."""
         b = self.board

@@ -248,12 +248,20 @@ class DeviceUpdateLog:
         nv.hip().ulog_mark_dead(self._own_ctl, 1 << rank, self.stream.cuda_stream)
 
     # ---------------------------------------------------------------------------------------------
-    def finish(self, final_version: Optional[int] = None) -> None:
+    def finish(self, final_version: Optional[int] = None, collective: bool = True) -> None:
         """End of training, called by all replicas after the last contribution (and after the chief
-        stopped its timer): applies what is still closed-but-unapplied until everybody agrees."""
+        stopped its timer): applies what is still closed-but-unapplied until everybody agrees.
+        collective=False (a worker died): one last catch-up, no agreement round."""
         if self._closed:
             return
         self.stream.synchronize()
+        if not collective:
+            sync, self.sync_status = self.sync_status, True
+            try:
+                self._launch(self._last_lr, MODE_CATCH_UP)
+            finally:
+                self.sync_status = sync
+            return
         self.comm.barrier()
         lr = self._last_lr
         deadline = time.time() + 60

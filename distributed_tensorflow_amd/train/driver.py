@@ -225,6 +225,27 @@ def train(flags, model: str) -> Dict:
         log.info("Worker %d: aggregation policy %s over %d replicas (aggregate %d)", rank, strategy.name, world, num_replicas_to_aggregate)
 
     timeout_client, timeout_server = control_plane.launch_manager(board, rank, world, flags.collective_timeout_s)
+    watchdog = None
+    if board is not None and world > 1:
+        silence = flags.liveness_timeout_s if flags.liveness_timeout_s > 0 else flags.collective_timeout_s / 4.0
+
+        def tolerate(dead) -> bool:
+            # policies on the update log go on while enough replicas are left to make an update
+            if strategy is None or not strategy.uses_update_log:
+                return False
+            if strategy.name == "backup":
+                return world - len(dead) >= strategy.m
+            if strategy.name == "interval":
+                return 0 not in dead       # the chief's timer closes the windows
+            return False
+
+        def on_dead(r: int) -> None:
+            lg = getattr(strategy, "log", None)
+            if lg is not None and hasattr(lg, "mark_dead"):
+                lg.mark_dead(r)
+
+        watchdog = control_plane.Watchdog(board, rank, world, silence, tolerate, on_dead)
+        watchdog.start()
     timeline = StepTimeline(rank, enabled=flags.timeline_logging)
     if flags.timeline_logging:
         replica.timeline = timeline        # traced steps: one event per kernel, phase spans from the policy
@@ -271,8 +292,17 @@ def train(flags, model: str) -> Dict:
             if board.global_step() > flags.max_steps:
                 board.request_stop()
         else:
-            with timeline.span("train_step", getattr(replica, "stream", None)):
-                res = strategy.step(replica, cur_iteration, lr_schedule)
+            try:
+                with timeline.span("train_step", getattr(replica, "stream", None)):
+                    res = strategy.step(replica, cur_iteration, lr_schedule)
+            except RuntimeError as e:
+                # A collective that lost its peer fails at once on some transports (TCP resets) and
+                # hangs on others; either way the liveness watchdog is the one that says WHO died and
+                # ends the process. Give it its time before passing the transport's error on.
+                if watchdog is not None:
+                    log.error("Worker %d: step failed (%s); waiting for the liveness verdict", rank, str(e).splitlines()[0][:200])
+                    watchdog.join(timeout=2.0 * watchdog.silence_s + 5.0)
+                raise
             if res.global_step is not None:
                 global_step = res.global_step     # a replica that catches up applies several updates in one call
             elif res.applied:
@@ -342,15 +372,14 @@ def train(flags, model: str) -> Dict:
                 sv.maybe_save(step, replica.updates_applied, force=True)
         else:
             sv.maybe_save(step, replica.updates_applied)
-        if board is not None:
-            board.heartbeat(rank)
+    lost = board is not None and board.agg_dead() != 0   # workers the watchdog gave up on: no collective can include them
 
     if async_mode:
         shards.drain(flags.collective_timeout_s)
         global_step = board.global_step()
         shards.close()
     if strategy is not None:
-        strategy.finish()
+        strategy.finish(collective=not lost)
         if strategy.uses_update_log:
             global_step = replica.updates_applied
         if sharded:
@@ -362,7 +391,10 @@ def train(flags, model: str) -> Dict:
     final = sv.final_save(global_step, replica.updates_applied)
     if summary_writer is not None:
         summary_writer.close()
-    comm.barrier()
+    if watchdog is not None:
+        watchdog.depart()
+    if not lost:
+        comm.barrier()
     if board is not None and is_chief:
         board.request_stop()
     out = {
@@ -372,5 +404,8 @@ def train(flags, model: str) -> Dict:
     }
     if async_mode:
         out["async_stats"] = vars(shards.stats)
-    comm.close()
+    if lost:
+        out["dead_workers"] = [r for r in range(world) if (board.agg_dead() >> r) & 1]
+    else:
+        comm.close()      # tearing the process group down would wait for the dead worker
     return out

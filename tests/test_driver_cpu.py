@@ -225,3 +225,67 @@ def test_timeline_json_carries_kernel_events_and_phase_spans(tmp_path):
     phases = {e["name"]: (e["ts"], e["dur"]) for e in ev if e.get("cat") == "phase"}
     assert phases["forward"] == (3.0, 40.0) and phases["backward"] == (50.0, 30.0)
     assert any(e.get("cat") == "host" and e["name"] == "train_step" for e in ev)
+
+
+def _start_ranks(world, extra, train_dir, port):
+    from distributed_tensorflow_amd.launch import rank_environment
+
+    procs, logs = [], []
+    for r in range(world):
+        env = rank_environment(r, world, port, 0, dict(os.environ, OMP_NUM_THREADS="1"))
+        logf = open(os.path.join(train_dir, f"rank{r}.log"), "w")
+        logs.append(logf)
+        procs.append(subprocess.Popen(
+            [sys.executable, "DistributedLeNet/src/mnist_distributed_train.py", "--synthetic_data", "--device=cpu", "--batch_size=8",
+             f"--train_dir={train_dir}", "--initial_learning_rate=0.001", "--save_interval_secs=100000",
+             "--liveness_timeout_s=2", "--inject_straggler_ms=20", "--inject_straggler_ranks=0,1,2"] + extra,
+            stdout=logf, stderr=subprocess.STDOUT, env=env, cwd=ROOT))
+    return procs, logs
+
+
+def _wait_for_step(path, step, timeout=120):
+    deadline = time.time() + timeout
+    while time.time() < deadline:
+        steps = [int(m.group(2)) for m in (TRAIN_RE.match(l) for l in open(path)) if m]
+        if steps and steps[-1] >= step:
+            return True
+        time.sleep(0.1)
+    return False
+
+
+@pytest.mark.parametrize("mode", ["sync", "backup"])
+def test_a_killed_worker_is_noticed_by_name(tmp_path, mode):
+    """Three workers, worker 2 is SIGKILLed mid-run. Full sync cannot go on: the survivors stop within
+    the liveness bound, non-zero, naming worker 2 (not after the process group's 600 s). Backup
+    workers with M = 2 of 3 finish their steps without it."""
+    import signal
+
+    from distributed_tensorflow_amd.launch import free_port
+
+    d = str(tmp_path)
+    extra = ["--max_steps=100000"] if mode == "sync" else ["--max_steps=120", "--backup_worker_method=true", "--num_replicas_to_aggregate=2"]
+    procs, logs = _start_ranks(3, extra, d, free_port())
+    try:
+        assert _wait_for_step(os.path.join(d, "rank2.log"), 3), open(os.path.join(d, "rank2.log")).read()[-2000:]
+        procs[2].send_signal(signal.SIGKILL)
+        t_kill = time.time()
+        rcs = [procs[r].wait(timeout=90) for r in (0, 1)]
+        took = time.time() - t_kill
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for f in logs:
+            f.close()
+    out = [open(os.path.join(d, f"rank{r}.log")).read() for r in range(3)]
+    for r in (0, 1):
+        assert "worker 2 has been silent" in out[r], out[r][-2000:]
+    if mode == "sync":
+        assert all(rc == 3 for rc in rcs), rcs                      # stopped by the watchdog, not by a collective timeout
+        assert took < 30, took
+        assert all("the job cannot continue" in out[r] for r in (0, 1))
+    else:
+        assert rcs == [0, 0], (rcs, out[0][-1500:])
+        assert all("continuing without it" in out[r] for r in (0, 1))
+        steps = [int(m.group(2)) for m in (TRAIN_RE.match(l) for l in out[0].splitlines()) if m]
+        assert steps[-1] >= 120
