@@ -247,6 +247,12 @@ class Communicator:
             "rccl_ranks": self.world if (self._collectives and self.info.backend == "nccl") else 0,
         }
 
+    def check_health(self) -> None:
+        """Raises if a hand-written collective reported a timeout since the last call. Reads a device
+        word, so call it where the stream is synchronised anyway (loss read-back, checkpoints)."""
+        if self.p2p is not None:
+            self.p2p.check()
+
     def enable_p2p(self, max_floats: int, **kw) -> None:
         """Routes all_reduce_async of GPU buffers through the peer-to-peer kernel."""
         from .p2p import P2PAllReduce

@@ -32,7 +32,9 @@ class P2PAllReduce:
         self.timeout_ticks = int(timeout_s * self.TICKS_PER_SECOND)
         self.seq = 0
         h = nv.hip()
-        self._own_x = h.ipc_alloc(self.capacity * 4, False)
+        # fine-grained: peers read this buffer while the owner's kernel is still running, so its
+        # lines must not sit in a non-coherent cache on either side
+        self._own_x = h.ipc_alloc(self.capacity * 4, True)
         self._own_f = h.ipc_alloc(int(h.P2P_FLAG_BLOCK_BYTES), True)
         handles = comm.all_gather_object((h.ipc_export(self._own_x), h.ipc_export(self._own_f)))
         self._xbuf: List[int] = []
@@ -66,9 +68,12 @@ class P2PAllReduce:
         return flat
 
     def check(self) -> None:
-        """Synchronises and raises if any wait inside the collective timed out."""
+        """Synchronises and raises if any wait inside the collective timed out. The error word is
+        sticky (every later call returns early with unreduced data), so callers look at it wherever
+        they synchronise anyway - the driver does at every loss read-back and before a checkpoint."""
         if int(self.error[0].item()) != 0:
-            raise RuntimeError("peer-to-peer all-reduce timed out waiting for a peer")
+            raise RuntimeError("peer-to-peer all-reduce timed out waiting for a peer; gradients since then were NOT reduced "
+                               "and the replicas have diverged - restart from the last checkpoint")
 
     def close(self) -> None:
         h = nv.hip()

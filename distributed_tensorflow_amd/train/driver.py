@@ -334,6 +334,7 @@ def train(flags, model: str) -> Dict:
         log_now = flags.log_every <= 1 or cur_iteration % flags.log_every == 0
         if log_now and not async_mode:
             loss_value = replica.loss_value()
+            comm.check_health()          # the stream is synchronised here anyway
         if log_now:
             assert not math.isnan(loss_value), "Model diverged with loss = NaN"
         if flags.timeline_logging:

@@ -52,7 +52,7 @@ class Evaluator:
         n = len(self.labels)
         self.batch = n if flags.eval_batch_size <= 0 else min(flags.eval_batch_size, n)
         self.replica = make_replica(model, self.batch, flags.device, num_residual_blocks=flags.num_residual_blocks,
-                                    optimizer=flags.optimizer, use_graph=False)
+                                    optimizer=flags.optimizer, use_graph=False, inference_only=True)
         self.saver = Saver(self.replica.arena, flags.optimizer, flags.checkpoint_names)
         self.last_step: Optional[int] = None
         self.writer = None
@@ -63,13 +63,13 @@ class Evaluator:
             log.info("No checkpoint file found")
             return None
         prefix = st[0]
+        global_step = step_of(prefix)
+        if self.last_step is not None and global_step == self.last_step:
+            return None                                     # already scored: nothing is read or copied
         try:
             self.saver.restore(prefix, strict=True)
         except (RuntimeError, KeyError, ValueError) as e:   # the trainer may be rotating files
             log.info("Could not load %s yet: %s", prefix, e)
-            return None
-        global_step = step_of(prefix)
-        if self.last_step is not None and global_step == self.last_step:
             return None
         self.last_step = global_step
         log.info(LOADED_LINE % (prefix, global_step))

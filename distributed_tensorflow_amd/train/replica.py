@@ -182,7 +182,7 @@ class HipReplica(ReplicaBase):
 
     def __init__(self, model: str, batch_size: int, *, num_residual_blocks: int = 18, optimizer: str = "adam",
                  momentum: float = 0.9, weight_decay: float = 0.0, seed: int = 66478, num_buckets: int = 1,
-                 use_graph: bool = True, abortable: bool = False):
+                 use_graph: bool = True, abortable: bool = False, inference_only: bool = False):
         from ..models.lenet_hip import LeNetHipStep
         from ..models.resnet_hip import ResNetHipStep
 
@@ -194,6 +194,16 @@ class HipReplica(ReplicaBase):
         self.arena = ParamArena(make_specs(model, num_residual_blocks), self.device, slots)
         self.arena.initialize(seed)
         self.stream = torch.cuda.Stream()
+        self._eval_steps = {}
+        self._event = torch.cuda.Event()
+        self.ctl_block = 0
+        self.step = None
+        self.use_graph = False
+        self.bucket_ranges = [(0, self.arena.total)]
+        if inference_only:
+            # an evaluator needs the parameters and an inference program per batch size (built on
+            # first use by evaluate()): no activations kept for backward, no gradient buffers
+            return
         # Short-circuiting (reference: DistributedLeNet/src/short_circuit_gradients.py:487-545): the
         # kernels of the step are recorded with the addresses of two words of a control block that
         # the update log adopts later; once "updates complete" rises above "updates applied" every
@@ -223,8 +233,6 @@ class HipReplica(ReplicaBase):
                 self.step.instantiate(per_segment=True)
         self.stream.synchronize()
         self.bucket_ranges = list(self.step.bucket_ranges)
-        self._eval_steps = {}
-        self._event = torch.cuda.Event()
 
     def stream_ctx(self):
         return torch.cuda.stream(self.stream)
@@ -343,4 +351,5 @@ def make_replica(model: str, batch_size: int, device: str = "auto", **kw) -> Rep
         return HipReplica(model, batch_size, **kw)
     kw.pop("use_graph", None)
     kw.pop("abortable", None)
+    kw.pop("inference_only", None)
     return TorchReplica(model, batch_size, device="cpu", **kw)
