@@ -92,7 +92,8 @@ def bench_policy(args) -> None:
     if args.mode == "async":
         from distributed_tensorflow_amd.parallel.async_ps import AsyncParameterShards
 
-        shards = AsyncParameterShards(replica, comm, board, args.staleness, name + "_ps", lambda version: args.lr)
+        shards = AsyncParameterShards(replica, comm, board, args.staleness, name + "_ps", args.lr)
+        shards.read_loss_every_step = False   # the host only enqueues: pull, step, push and the owners' applies are kernels
         step_fn = lambda i: shards.step()   # noqa: E731
     else:
         if args.mode == "backup":
@@ -180,7 +181,7 @@ def bench_policy(args) -> None:
     final_loss = replica.loss_value()
     if args.mode == "async":
         shards.drain(30.0)
-        detail["async_stats"] = vars(shards.stats)
+        detail["async_stats"] = dict(vars(shards.stats), staleness_histogram=list(shards.staleness_hist), shard_versions=shards.versions())
     t = torch.tensor([dt], device=comm.device, dtype=torch.float64)
     if world > 1:
         import torch.distributed as dist

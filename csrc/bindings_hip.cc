@@ -10,6 +10,7 @@
 
 #include "comm/p2p_allreduce.h"
 #include "comm/update_log.h"
+#include "comm/async_shards.h"
 #include "kernels/conv.h"
 #include "kernels/ops.h"
 #include "runtime/program.h"
@@ -312,6 +313,32 @@ PYBIND11_MODULE(_hip, m) {
     m.def("ulog_poke", [](uint64_t ctl, int word, unsigned long long value) {
       ulog_poke(reinterpret_cast<unsigned long long*>(ctl), word, value);
     });
+    // ---- asynchronous parameter shards
+    auto afill = [](const py::dict& d) {
+      AsyncArgs a{};
+      auto ctl = d["ctl"].cast<std::vector<uint64_t>>();
+      auto shard = d["shard"].cast<std::vector<uint64_t>>();
+      auto inbox = d["inbox"].cast<std::vector<uint64_t>>();
+      V(rank); V(world); V(shard_floats);
+      if ((int)ctl.size() != a.world || (int)shard.size() != a.world || (int)inbox.size() != a.world || a.world > kAsyncMaxPeers)
+        throw std::runtime_error("async shards: per-rank lists must have `world` (at most 8) entries");
+      for (int p = 0; p < a.world; ++p) {
+        a.ctl[p] = reinterpret_cast<unsigned long long*>(ctl[p]);
+        a.shard[p] = reinterpret_cast<float*>(shard[p]);
+        a.inbox[p] = reinterpret_cast<float*>(inbox[p]);
+      }
+      P(params, float); P(grads, const float); P(m, float); P(v, float); P(status, unsigned long long);
+      V(tau); V(opt); V(lr0); V(decay); V(decay_steps); V(beta1); V(beta2); V(eps); V(momentum); V(weight_decay);
+      V(timeout_ticks); V(push_wait_ticks);
+      return a;
+    };
+    m.def("async_pull", [afill](const py::dict& d, int blocks, uint64_t stream) { async_pull(afill(d), blocks, as_stream(stream)); });
+    m.def("async_push", [afill](const py::dict& d, int blocks, uint64_t stream) { async_push(afill(d), blocks, as_stream(stream)); });
+    m.def("async_service", [afill](const py::dict& d, int blocks, uint64_t stream) { async_service(afill(d), blocks, as_stream(stream)); });
+    m.attr("ASYNC_CTL_BYTES") = (uint64_t)kAsyncCtlBytes;
+    m.attr("ASYNC_HIST_BINS") = (int)kAsyncHistBins;
+    m.attr("AW_VERSION") = (int)AW_VERSION; m.attr("AW_ERROR") = (int)AW_ERROR; m.attr("AW_STATS") = (int)AW_STATS;
+    m.attr("AW_DOORBELL") = (int)AW_DOORBELL;
     m.attr("ULOG_CTL_BYTES") = (uint64_t)kUlogCtlBytes;
     m.attr("ULOG_RING") = (int)kUlogRing;
     m.attr("ULOG_WORD_BYTES") = (int)(kUlogWordStride * sizeof(unsigned long long));

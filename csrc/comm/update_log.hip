@@ -18,14 +18,16 @@
 #include <stdexcept>
 
 #include "../kernels/optim_math.h"
+#include "device_sync.h"
 
 namespace dtf {
 namespace {
 
-using u64 = unsigned long long;
+using namespace dsync;
+static_assert(kWordStride == kUlogWordStride, "control blocks use one word per 128-byte line");
 
 constexpr u64 kFrozen = 1ull << 31;
-constexpr u64 kActDone = 0, kActApply = 1, kActError = 2, kActOk = 3;
+constexpr u64 kActDone = 0, kActApply = 1, kActError = kVerdictError, kActOk = 3;
 
 enum UlogError : int {
   UE_BACKPRESSURE = 1,   // the slowest live replica did not catch up in time
@@ -35,17 +37,6 @@ enum UlogError : int {
   UE_READY = 5,          // an owner never published its reduced shard
   UE_FROZEN = 6,         // a window stayed frozen (its closer never opened the next one)
 };
-
-__device__ __forceinline__ u64* W(u64* ctl, int word) { return ctl + (size_t)word * kUlogWordStride; }
-__device__ __forceinline__ u64 ld(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ u64 ld_acq(const u64* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void st(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void st_rel(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ bool cas(u64* p, u64& expected, u64 desired) {
-  return __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ void acquire_fence() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
-__device__ __forceinline__ void nap() { __builtin_amdgcn_s_sleep(8); }
 
 __device__ __forceinline__ long long open_u(u64 w) { return (long long)(w >> 32); }
 __device__ __forceinline__ int open_count(u64 w) { return (int)((w >> 16) & 0x7fff); }
@@ -64,10 +55,12 @@ struct Rec {
 // 1: update u is closed (record in r); 0: not closed yet; -1: the slot already serves a later update
 __device__ __forceinline__ int read_hist(u64* own, long long u, Rec& r) {
   const int slot = (int)(u % kUlogRing);
-  const u64 t = ld_acq(W(own, UW_HIST_TAG + slot));
+  // relaxed first (this is what waits poll): an acquire at system scope invalidates cache lines
+  const u64 t = ld(W(own, UW_HIST_TAG + slot));
   const long long tu = (long long)(t >> 32) - 1;
   if (tu > u) return -1;
   if (tu != u) return 0;
+  acquire_fence();
   const u64 aux = ld(W(own, UW_HIST_AUX + slot));
   if (ld_acq(W(own, UW_HIST_TAG + slot)) != t) return -1;
   r.count = (int)((t >> 16) & 0xffff);
@@ -229,52 +222,6 @@ __global__ void ulog_begin_kernel(UlogArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <typename F>
-__device__ __forceinline__ u64 leader_step(const UlogArgs& a, u64* own, u64 seq, int& nsync, u64* s_payload, F&& fn) {
-  __threadfence_system();   // this block's data is visible before anything the leader publishes
-  __syncthreads();
-  ++nsync;
-  if (threadIdx.x == 0) {
-    const u64 tag = (seq << 16) | (u64)nsync;
-    u64* cnt = W(own, UW_COUNTER);
-    __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    const long long t0 = wall_clock64();
-    u64 payload = kActError;
-    if (blockIdx.x == 0) {
-      const u64 want = (u64)nsync * gridDim.x;
-      bool ok = true;
-      while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        if (wall_clock64() - t0 > a.timeout_ticks) {
-          ok = false;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (ok)
-        payload = fn();
-      else
-        raise_error(own, UE_GRID);
-      st(W(own, UW_DEC_VAL + (nsync & 3)), payload);
-      __hip_atomic_store(W(own, UW_DEC_TAG + (nsync & 3)), tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      u64* tg = W(own, UW_DEC_TAG + (nsync & 3));
-      bool ok = true;
-      // the leader's own waits may take several timeouts before it gives up
-      while (__hip_atomic_load(tg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) {
-        if (wall_clock64() - t0 > 4 * a.timeout_ticks) {
-          ok = false;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (ok) payload = ld(W(own, UW_DEC_VAL + (nsync & 3)));
-    }
-    *s_payload = payload;
-  }
-  __syncthreads();
-  return *s_payload;
-}
-
 // Leader only: what to do about update u. wait_u: the update this launch must see closed.
 __device__ u64 next_action(const UlogArgs& a, u64* own, long long u, long long wait_u) {
   if (ld(W(own, UW_ERROR)) != 0) return kActError;
@@ -312,7 +259,7 @@ __global__ __launch_bounds__(256) void ulog_step_kernel(UlogArgs a) {
   const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long gstride = (long long)gridDim.x * blockDim.x;
   long long version = (long long)ld(W(own, UW_VERSION));
-  int nsync = 0;
+  LeaderCtx lc{W(own, UW_COUNTER), W(own, UW_DEC_TAG), W(own, UW_DEC_VAL), seq, a.timeout_ticks};
 
   // ---- stage ------------------------------------------------------------------------------------------
   if (op != 0) {
@@ -328,7 +275,7 @@ __global__ __launch_bounds__(256) void ulog_step_kernel(UlogArgs a) {
   // leader-only state (block 0, thread 0)
   long long wait_u = -1;
   u64 last_flags = 0, applied_now = 0, contributors = 0;
-  u64 act = leader_step(a, own, seq, nsync, &s_payload, [&]() -> u64 {
+  u64 act = leader_step(lc, &s_payload, [&]() -> u64 {
     if (op != 0) {
       int order = 0;
       bool closed = false;
@@ -378,7 +325,7 @@ __global__ __launch_bounds__(256) void ulog_step_kernel(UlogArgs a) {
         out[i] = acc;
       }
     }
-    u64 ok = leader_step(a, own, seq, nsync, &s_payload, [&]() -> u64 {
+    u64 ok = leader_step(lc, &s_payload, [&]() -> u64 {
       if (owner)
         for (int p = 0; p < a.world; ++p) st_rel(W(a.ctl[p], UW_READY + slot * kUlogMaxPeers + a.rank), (u64)(version + 1));
       const long long t0 = wall_clock64();
@@ -431,7 +378,7 @@ __global__ __launch_bounds__(256) void ulog_step_kernel(UlogArgs a) {
         m4[i] = m;
       }
     }
-    act = leader_step(a, own, seq, nsync, &s_payload, [&]() -> u64 {
+    act = leader_step(lc, &s_payload, [&]() -> u64 {
       st(W(own, UW_VERSION), (u64)(version + 1));
       for (int p = 0; p < a.world; ++p) st_rel(W(a.ctl[p], UW_APPLIED + a.rank), (u64)(version + 1));
       ++applied_now;
@@ -443,6 +390,7 @@ __global__ __launch_bounds__(256) void ulog_step_kernel(UlogArgs a) {
 
   // ---- bookkeeping (leader) ---------------------------------------------------------------------------
   if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (act == kActError) raise_error(own, UE_GRID);   // keeps an earlier, more specific code if there is one
     st(W(own, UW_STATS + US_VERSION), ld(W(own, UW_VERSION)));
     st(W(own, UW_STATS + US_APPLIED), applied_now);
     st(W(own, UW_STATS + US_LAST), last_flags);

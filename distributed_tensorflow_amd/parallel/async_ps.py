@@ -49,11 +49,21 @@ class AsyncStats:
     pushed: int = 0
     applied: int = 0
     dropped_stale: int = 0
-    push_waits: int = 0
+    push_waits: int = 0            # host: polls spent waiting for an inbox slot; device: pushes given up on a busy slot
 
 
 class AsyncParameterShards:
-    """Shard ownership, peer mappings and the push / pull / apply protocol."""
+    """Shard ownership, peer mappings and the push / pull / apply protocol. This class is the host
+    implementation (CPU replicas; data in shared file mappings, doorbells on the board); for GPU
+    replicas the constructor hands back `async_ps_hip.DeviceAsyncShards`, the same protocol run by
+    kernels over peer-mapped HBM."""
+
+    def __new__(cls, replica, *args, **kw):
+        if cls is AsyncParameterShards and replica.arena.params.is_cuda:
+            from .async_ps_hip import DeviceAsyncShards
+
+            return object.__new__(DeviceAsyncShards)
+        return object.__new__(cls)
 
     def __init__(self, replica, comm: Communicator, board, staleness_bound: int, name: str, lr_fn,
                  push_timeout_s: float = 30.0):
@@ -67,6 +77,7 @@ class AsyncParameterShards:
         self.lr_fn = lr_fn
         self.push_timeout_s = push_timeout_s
         self.stats = AsyncStats()
+        self.staleness_hist: List[int] = [0] * 16
         self.on_gpu = self.arena.params.is_cuda
         self._name = name.strip("/").replace("/", "_")
         self._pulled_version: List[int] = [0] * self.world
@@ -165,6 +176,7 @@ class AsyncParameterShards:
             if pushed_step < 0:
                 continue
             version = self.board.shard_version(me)
+            self.staleness_hist[min(15, max(0, version - pushed_step))] += 1
             if version - pushed_step <= self.tau:
                 if n > 0:
                     self._apply(self.inboxes[me][s][:n], version)
@@ -181,7 +193,7 @@ class AsyncParameterShards:
     def _apply(self, grad: torch.Tensor, version: int) -> None:
         a = self.arena
         lo, hi = self.bounds[self.rank]
-        lr = self.lr_fn(version)
+        lr = self.lr_fn(version) if callable(self.lr_fn) else float(self.lr_fn)
         shard = self.shards[self.rank][: hi - lo]
         opt = self.replica.optimizer
         if self.on_gpu:
@@ -212,6 +224,10 @@ class AsyncParameterShards:
         self.push()
         self.service()
         return self.replica.loss_value(), self.board.global_step()
+
+    def versions(self) -> List[int]:
+        """Updates applied to every shard so far."""
+        return [int(self.board.shard_version(o)) for o in range(self.world)]
 
     def drain(self, timeout_s: float = 30.0) -> None:
         """End of training: keep servicing the own shard until every replica has stopped pushing

@@ -215,7 +215,7 @@ def train(flags, model: str) -> Dict:
             board = control_plane.open_board(name + "_b", world, rank)
         shards = AsyncParameterShards(
             replica, comm, board, flags.staleness_bound, name,
-            lambda version: lr_mod.exponential_decay(flags.initial_learning_rate, version, decay_steps, flags.learning_rate_decay_factor),
+            lr_mod.StaircaseSchedule(flags.initial_learning_rate, decay_steps, flags.learning_rate_decay_factor),
         )
         board.set_global_step(global_step) if is_chief else None
         strategy = None
@@ -404,7 +404,7 @@ def train(flags, model: str) -> Dict:
         "strategy": "async" if async_mode else strategy.name,
     }
     if async_mode:
-        out["async_stats"] = vars(shards.stats)
+        out["async_stats"] = dict(vars(shards.stats), staleness_histogram=list(shards.staleness_hist))
     if lost:
         out["dead_workers"] = [r for r in range(world) if (board.agg_dead() >> r) & 1]
     else:

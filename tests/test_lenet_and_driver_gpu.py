@@ -173,7 +173,7 @@ def _gpu_async_worker(rank, world, board_name):
     shards.drain(60)
     rep.synchronize()
     out = dict(losses=losses, psum=rep.arena.params.double().sum().item(), stats=vars(shards.stats),
-               versions=[board.shard_version(o) for o in range(world)])
+               versions=shards.versions(), hist=list(shards.staleness_hist), kind=type(shards).__name__)
     shards.close()
     comm.barrier()
     comm.close()
@@ -182,7 +182,9 @@ def _gpu_async_worker(rank, world, board_name):
 
 def test_async_parameter_shards_in_hbm_over_ipc():
     out = run_workers(_gpu_async_worker, 2, f"dtf_g_async_{os.getpid()}", timeout=300)
+    assert all(o["kind"] == "DeviceAsyncShards" for o in out)          # kernels over IPC-mapped HBM, not the host path
     assert out[0]["versions"] == [16, 16]
     assert sum(o["stats"]["applied"] for o in out) == 32
+    assert all(sum(o["hist"]) == 16 and sum(o["hist"][9:]) == 0 for o in out)   # every push applied within the bound (8)
     assert abs(out[0]["psum"] - out[1]["psum"]) < 1e-6 * max(1.0, abs(out[0]["psum"]))
     assert out[0]["losses"][-1] < out[0]["losses"][0]

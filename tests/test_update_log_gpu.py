@@ -221,3 +221,45 @@ def test_soft_kill_straggler_pushes_zeros_and_the_mean_is_over_all_replicas():
     count, mask, owners, scale = out[0]["entry"]
     assert count == world and mask == 0b111 and abs(scale - 1.0 / world) < 1e-7
     assert all(o["version"] == 1 for o in out) and len({o["psum"] for o in out}) == 1
+
+
+def _async_busy_owner_worker(rank, world, board_name):
+    from distributed_tensorflow_amd.ops import native as nv
+    from distributed_tensorflow_amd.parallel.async_ps import AsyncParameterShards
+
+    comm, board, rep = _setup(rank, world, board_name)
+    shards = AsyncParameterShards(rep, comm, board, 8, board_name + "_ps", 1e-3)
+    h = nv.hip()
+    seen = []
+    comm.barrier()
+    if rank == 1:
+        # the owner of shard 1 is "inside its step": its training thread is asleep; its service
+        # thread keeps sweeping the shard's doorbells
+        time.sleep(1.5)
+    else:
+        shards.read_loss_every_step = False
+        for k in range(3):
+            t0 = time.time()
+            shards.pull()
+            rep.forward_backward()
+            shards.push()
+            rep.synchronize()
+            want = k + 1
+            while time.time() - t0 < 1.0 and shards.versions()[1] < want:
+                time.sleep(0.002)
+            seen.append((shards.versions()[1], time.time() - t0))
+    comm.barrier()
+    shards.drain(30)
+    out = dict(seen=seen, versions=shards.versions(), applied=shards.stats.applied)
+    shards.close()
+    comm.barrier()
+    comm.close()
+    return out
+
+
+def test_async_owner_applies_a_peers_push_while_it_is_busy():
+    out = run_workers(_async_busy_owner_worker, 2, f"dtf_gu_as_{os.getpid()}", timeout=300)
+    # all three pushes of rank 0 reached shard 1 long before its owner's host woke up (1.5 s)
+    assert [v for v, _ in out[0]["seen"]] == [1, 2, 3], out[0]["seen"]
+    assert sum(dt for _, dt in out[0]["seen"]) < 1.2, out[0]["seen"]
+    assert out[0]["versions"][1] == 3
