@@ -263,3 +263,37 @@ def test_async_owner_applies_a_peers_push_while_it_is_busy():
     assert [v for v, _ in out[0]["seen"]] == [1, 2, 3], out[0]["seen"]
     assert sum(dt for _, dt in out[0]["seen"]) < 1.2, out[0]["seen"]
     assert out[0]["versions"][1] == 3
+
+
+def test_short_circuit_in_the_middle_of_backward_leaves_zeros_beyond_the_cut():
+    """The abort word rises between two segments of the backward pass: what was computed before stays,
+    every kernel after the cut returns within launch latency (per-kernel times from a traced replay)
+    and the gradients of the layers not reached are the zeros of the step prologue."""
+    from distributed_tensorflow_amd.ops import native as nv
+    from distributed_tensorflow_amd.train.replica import HipReplica
+
+    h = nv.hip()
+    rep = HipReplica("resnet", 256, num_residual_blocks=3, num_buckets=3, abortable=True)
+    g = torch.Generator().manual_seed(5)
+    rep.load_batch(torch.randn(256, 32, 32, 3, generator=g), torch.randint(0, 10, (256,), generator=g))
+    st = rep.step
+    assert st.num_segments == 4                      # three gradient buckets + the optimizer
+    with torch.cuda.stream(rep.stream):
+        full = [st.run_traced(i) for i in range(3)]
+        rep.stream.synchronize()
+        ranges = st.bucket_ranges
+        assert all(float(rep.arena.grads[lo:hi].abs().sum()) > 0 for lo, hi in ranges)
+        first = st.run_traced(0)                      # forward + the last layers' backward
+        rep.stream.synchronize()
+        h.ulog_poke(rep.ctl_block, int(h.UW_ABORT), 1)
+        cut = [st.run_traced(i) for i in (1, 2)]
+        rep.stream.synchronize()
+    lo0, hi0 = ranges[0]
+    assert float(rep.arena.grads[lo0:hi0].abs().sum()) > 0                     # reached before the cut
+    for lo, hi in ranges[1:]:
+        assert float(rep.arena.grads[lo:hi].abs().sum()) == 0.0                # never reached
+    conv_full = [e for seg in full[1:] for e in seg if "conv" in e[0]]
+    conv_cut = [e for seg in cut for e in seg if "conv" in e[0]]
+    assert len(conv_cut) == len(conv_full) >= 10                               # one abort point per kernel
+    assert max(e[4] for e in conv_cut) < 15.0, sorted(e[4] for e in conv_cut)[-3:]   # microseconds
+    assert sum(e[4] for e in conv_cut) < 0.3 * sum(e[4] for e in conv_full)
