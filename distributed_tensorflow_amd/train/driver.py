@@ -129,7 +129,7 @@ def train(flags, model: str) -> Dict:
         return {"role": "ps"}
     task.export()
     device = flags.device
-    comm = Communicator.from_env(device="cpu" if device == "cpu" else None)
+    comm = Communicator.from_env(backend=flags.comm_backend or None, device="cpu" if device == "cpu" else None)
     world, rank = comm.world, comm.rank
     is_chief = rank == 0
     num_workers = world
@@ -409,4 +409,7 @@ def train(flags, model: str) -> Dict:
         out["dead_workers"] = [r for r in range(world) if (board.agg_dead() >> r) & 1]
     else:
         comm.close()      # tearing the process group down would wait for the dead worker
+    import json
+
+    log.info("RESULT %s", json.dumps(out, default=str))
     return out

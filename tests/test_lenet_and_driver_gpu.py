@@ -188,3 +188,54 @@ def test_async_parameter_shards_in_hbm_over_ipc():
     assert all(sum(o["hist"]) == 16 and sum(o["hist"][9:]) == 0 for o in out)   # every push applied within the bound (8)
     assert abs(out[0]["psum"] - out[1]["psum"]) < 1e-6 * max(1.0, abs(out[0]["psum"]))
     assert out[0]["losses"][-1] < out[0]["losses"][0]
+
+
+@pytest.mark.parametrize("mode", ["backup", "interval", "async", "soft_kill"])
+def test_driver_runs_the_straggler_policies_on_the_device_update_log(tmp_path, mode):
+    """Entry script -> driver -> policy, two workers sharing GPU 0 (gloo carries the set-up exchange, the
+    aggregation itself runs in kernels over IPC-mapped HBM): both reach max_steps, the chief's
+    checkpoint carries the final global step and worker 1 (slowed down) is the one whose gradients
+    are dropped in backup mode."""
+    import json
+
+    from distributed_tensorflow_amd.checkpoint.saver import latest_checkpoint, read_bundle
+    from distributed_tensorflow_amd.launch import free_port, rank_environment
+
+    d = str(tmp_path)
+    extra = {"backup": ["--backup_worker_method=true", "--num_replicas_to_aggregate=1"],
+             "interval": ["--interval_method=true", "--interval_ms=3"],
+             "async": ["--async_method=true", "--staleness_bound=8"],
+             "soft_kill": ["--soft_kill_method=true", "--should_stop_worker_num=1"]}[mode]
+    port = free_port()
+    procs, logs = [], []
+    for r in range(2):
+        env = rank_environment(r, 2, port, 1, dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        logf = open(os.path.join(d, f"rank{r}.log"), "w")
+        logs.append(logf)
+        procs.append(subprocess.Popen(
+            [sys.executable, "DistributedResNet/src/resnet_distributed_train.py", "--synthetic_data", "--batch_size=32",
+             "--num_residual_blocks=1", "--max_steps=30", f"--train_dir={d}", "--initial_learning_rate=0.001",
+             "--comm_backend=gloo", "--save_interval_secs=100000", "--inject_straggler_ms=5", "--inject_straggler_ranks=1"] + extra,
+            stdout=logf, stderr=subprocess.STDOUT, env=env, cwd=ROOT))
+    try:
+        rcs = [p.wait(timeout=280) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for f in logs:
+            f.close()
+    out = [open(os.path.join(d, f"rank{r}.log")).read() for r in range(2)]
+    assert rcs == [0, 0], (rcs, out[0][-2500:], out[1][-2500:])
+    ck = read_bundle(latest_checkpoint(d))
+    assert int(ck["global_step"]) >= 30
+    results = [json.loads(l.split("RESULT ", 1)[1]) for o in out for l in o.splitlines() if "RESULT {" in l]
+    assert len(results) == 2
+    # a worker that catches up applies several updates per iteration, so its log lines skip steps:
+    # what every worker must reach is the global step
+    assert all(r["global_step"] > 30 for r in results), results
+    steps0 = [int(m.group(1)) for m in (re.match(r".*step (\d+), loss = ", l) for l in out[0].splitlines()) if m]
+    assert steps0 and steps0[-1] >= 29
+    if mode == "backup":
+        by_rank = {r["rank"]: r for r in results}
+        assert by_rank[1]["excluded_steps"] > by_rank[0]["excluded_steps"]
