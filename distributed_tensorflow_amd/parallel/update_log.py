@@ -153,6 +153,8 @@ class HostUpdateLog:
         every closed update it has not applied yet."""
         a = self.replica.arena
         e = self.version
+        if e >= self.max_version:                     # the run is over: nothing is offered any more
+            return ContributionResult(False, -1, self.catch_up(lr), self.version)
         self._throttle(e)
         st = self.stage[self.rank]
         if weight == 1.0:
@@ -199,7 +201,7 @@ class HostUpdateLog:
             else:
                 st.copy_(a.grads)
             open_u = b.agg_open_update()
-            if max_staleness >= 0 and open_u - self.version > max_staleness:
+            if (max_staleness >= 0 and open_u - self.version > max_staleness) or open_u >= self.max_version:
                 self._pending = None
                 self.dropped += 1
                 accepted, order = False, -1

@@ -222,6 +222,15 @@ def train(flags, model: str) -> Dict:
     else:
         strategy = make_strategy(flags, comm, board, num_replicas_to_aggregate)
         strategy.start_version = global_step
+        if strategy.uses_update_log and world > 1 and board is not None:
+            ulog = strategy._get_log(replica)
+            # nobody offers a gradient for an update beyond the end of the run, so a worker that reads
+            # the (lagging) counters late cannot push the global step past max_steps + 1
+            ulog.max_version = flags.max_steps + 1
+            if hasattr(ulog, "sync_status"):
+                # with a loss read-back every step the stream is synchronised anyway; otherwise the
+                # host only enqueues and reads the counters the kernels mirror into pinned memory
+                ulog.sync_status = flags.log_every <= 1
         log.info("Worker %d: aggregation policy %s over %d replicas (aggregate %d)", rank, strategy.name, world, num_replicas_to_aggregate)
 
     timeout_client, timeout_server = control_plane.launch_manager(board, rank, world, flags.collective_timeout_s)

@@ -190,7 +190,7 @@ def test_async_parameter_shards_in_hbm_over_ipc():
     assert out[0]["losses"][-1] < out[0]["losses"][0]
 
 
-@pytest.mark.parametrize("mode", ["backup", "interval", "async", "soft_kill"])
+@pytest.mark.parametrize("mode", ["backup", "backup_unsynced", "interval", "async", "soft_kill"])
 def test_driver_runs_the_straggler_policies_on_the_device_update_log(tmp_path, mode):
     """Entry script -> driver -> policy, two workers sharing GPU 0 (gloo carries the set-up exchange, the
     aggregation itself runs in kernels over IPC-mapped HBM): both reach max_steps, the chief's
@@ -203,6 +203,8 @@ def test_driver_runs_the_straggler_policies_on_the_device_update_log(tmp_path, m
 
     d = str(tmp_path)
     extra = {"backup": ["--backup_worker_method=true", "--num_replicas_to_aggregate=1"],
+             # loss read back every 4th iteration only: the host never waits for the GPU in between
+             "backup_unsynced": ["--backup_worker_method=true", "--num_replicas_to_aggregate=1", "--log_every=4"],
              "interval": ["--interval_method=true", "--interval_ms=3"],
              "async": ["--async_method=true", "--staleness_bound=8"],
              "soft_kill": ["--soft_kill_method=true", "--should_stop_worker_num=1"]}[mode]
@@ -235,7 +237,7 @@ def test_driver_runs_the_straggler_policies_on_the_device_update_log(tmp_path, m
     # what every worker must reach is the global step
     assert all(r["global_step"] > 30 for r in results), results
     steps0 = [int(m.group(1)) for m in (re.match(r".*step (\d+), loss = ", l) for l in out[0].splitlines()) if m]
-    assert steps0 and steps0[-1] >= 29
+    assert steps0 and steps0[-1] >= (20 if mode == "backup_unsynced" else 29)
     if mode == "backup":
         by_rank = {r["rank"]: r for r in results}
         assert by_rank[1]["excluded_steps"] > by_rank[0]["excluded_steps"]
