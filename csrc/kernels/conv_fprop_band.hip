@@ -17,6 +17,7 @@
 // stride-2 layer); BWD instances apply the ReLU mask and accumulate BatchNorm-backward's sums.
 // (reference ops: conv2d / conv2d_backprop_input, DistributedResNet/src/resnet.py:99,121,150)
 #include "conv.h"
+#include "lds_banking.h"
 
 #include <cstdlib>
 
@@ -25,12 +26,14 @@ namespace {
 
 template <int S, int CP, int NT, int TW, int TH, bool UPS>
 struct FBand {
-  static constexpr int CPP = CP + 4;
   static constexpr int CG = CP / 16;
   static constexpr int KG = 9 * CG;
   static constexpr int C4 = CP / 4;
   static constexpr int LH = (TH - 1) * S + 3;
   static constexpr int LW = (TW - 1) * S + 3;
+  // per-pixel stride of the staged tile: the padding (4 or 8 floats) that keeps the 16-lane groups
+  // of the A-operand ds_read_b128 off each other's banks (lds_banking.h)
+  static constexpr int CPP = CP + lds_best_pad(CP, TW, LW, S);
   // stride 1: the halo tile's first and last column lie outside the image for every band; they are
   // zeroed once and only the TW image columns are staged (8-row bands: exactly 5 chunks per thread)
   static constexpr bool INTERIOR = (S == 1) && !UPS;
