@@ -28,6 +28,7 @@ import torch
 
 from .. import _host
 from ..runtime.arena import ParamArena
+from .meta_graph import write_meta
 
 CKPT_BASENAME = "model.ckpt"
 _NP_DTYPES = {_host.DT_FLOAT: np.float32, _host.DT_DOUBLE: np.float64, _host.DT_INT32: np.int32, _host.DT_INT64: np.int64}
@@ -134,6 +135,10 @@ class Saver:
         prefix = os.path.join(train_dir, f"{CKPT_BASENAME}-{global_step}")
         with self._lock:
             write_bundle(prefix, snap)
+            # the MetaGraphDef TensorFlow's Saver puts next to every bundle (variable list + SaverDef)
+            trainable = {self.var_name(s) for s in self.arena.specs if s.trainable}
+            write_meta(prefix, [(n, _DT_OF[np.asarray(t).dtype], list(np.shape(t)), n in trainable) for n, t in snap.items()],
+                       self.max_to_keep)
             if prefix in self._kept:
                 self._kept.remove(prefix)
             self._kept.append(prefix)

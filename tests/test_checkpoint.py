@@ -147,3 +147,35 @@ def test_max_to_keep_rotates_files(tmp_path):
     assert "model.ckpt-1.index" not in files and "model.ckpt-3.index" in files and "model.ckpt-2.index" in files
     latest, allp = get_checkpoint_state(str(tmp_path))
     assert latest.endswith("model.ckpt-3") and len(allp) == 2
+
+
+def test_meta_graph_file_lists_the_saved_variables(tmp_path):
+    """Every checkpoint comes with a `.meta` MetaGraphDef naming the same variables as the bundle
+    (VariableV2 nodes with dtype and shape, the variables / trainable_variables collections, a V2
+    SaverDef). TensorFlow is not importable here: the file is decoded with the module's own
+    wire-format reader, loading it with tf.train.import_meta_graph is unpinned."""
+    import numpy as np
+
+    from distributed_tensorflow_amd.checkpoint.meta_graph import DT_FLOAT, DT_INT32, build_meta_graph, read_meta
+    from distributed_tensorflow_amd.checkpoint.saver import Saver, bundle_names
+    from distributed_tensorflow_amd.models.lenet import lenet_param_specs
+    from distributed_tensorflow_amd.runtime.arena import ParamArena
+
+    a = ParamArena(lenet_param_specs(), "cpu", ("m", "v"))
+    a.initialize(1)
+    prefix = Saver(a, "adam").save(str(tmp_path), 7, 7)
+    meta = read_meta(prefix + ".meta")
+    assert sorted(meta["variables"]) == sorted(bundle_names(prefix))
+    assert meta["variables"]["Variable"] == (DT_FLOAT, [5, 5, 1, 32]) and meta["variables"]["global_step"] == (DT_INT32, [])
+    assert meta["variables"]["Variable_4/Adam_1"] == (DT_FLOAT, [3136, 512])
+    assert meta["collections"]["trainable_variables"] == [f"Variable_{i}" if i else "Variable" for i in range(8)]
+    assert set(meta["collections"]["variables"]) == set(meta["variables"])
+    assert meta["saver"][1] == "save/Const:0" and meta["saver"][4] == 5 and meta["saver"][7] == 2
+    # golden bytes of a one-variable graph: field numbers and nesting as in the .proto files
+    blob = build_meta_graph([("w", DT_FLOAT, [2, 3], True)], max_to_keep=1)
+    assert blob[:4] == b"\n\x1e\n\x00"                                   # MetaGraphDef.meta_info_def { meta_graph_version: "" ...
+    assert b"\n\x01w\x12\nVariableV2" in blob                            # NodeDef { name: "w" op: "VariableV2"
+    assert b"*\x0b\n\x05dtype\x12\x020\x01" in blob                       # attr { key: "dtype" value { type: DT_FLOAT } }
+    assert b"*\x13\n\x05shape\x12\n:\x08\x12\x02\x08\x02\x12\x02\x08\x03" in blob   # shape { dim { size: 2 } dim { size: 3 } }
+    assert b"\n\x03w:0\x12\x08w/Assign\x1a\x08w/read:0" in blob           # VariableDef
+    assert b"\n\x0csave/Const:0" in blob and blob.count(b"\"\x02\x08\x15") == 1   # SaverDef; GraphDef.versions { producer: 21 }
