@@ -187,6 +187,14 @@ class Watchdog(threading.Thread):
         while not self._stop_evt.wait(self.period_s):
             b.heartbeat(self.rank)
             if b.should_stop():
+                # a normal end of the run - or another worker's watchdog was faster: its verdict is on the board
+                mask = b.agg_dead()
+                gone = {r for r in range(self.world) if (mask >> r) & 1}
+                if gone - self.dead and not self.tolerate(gone | self.dead):
+                    for r in sorted(gone - self.dead):
+                        log.error("Worker %d: worker %d has been silent and is taken for dead (declared by another worker); "
+                                  "the job cannot continue, stopping", self.rank, r)
+                    self._exit_now()
                 return
             now = b.now_ns()
             for r in range(self.world):
@@ -215,6 +223,9 @@ class Watchdog(threading.Thread):
         log.error("Worker %d: worker %d has been silent for %.1f s and is taken for dead; the job cannot continue, stopping",
                   self.rank, r, silent_s)
         b.request_stop()
+        self._exit_now()
+
+    def _exit_now(self) -> None:
         for h in log.handlers + logging.getLogger().handlers:
             try:
                 h.flush()

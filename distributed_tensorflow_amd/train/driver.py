@@ -161,11 +161,14 @@ def train(flags, model: str) -> Dict:
     decay_steps = lr_mod.decay_steps(feed.num_examples, batch_size, flags.num_epochs_per_decay, num_replicas_to_aggregate)
 
     # ---- replica + strategy
-    strategy_needs_segments = flags.interval_method or flags.soft_kill_method or flags.backup_worker_method
+    uses_log = flags.interval_method or flags.soft_kill_method or flags.backup_worker_method or \
+        getattr(flags, "weighted_grads_method", False) or flags.async_method
     if flags.grad_buckets > 0:
         buckets = flags.grad_buckets
-    elif strategy_needs_segments:
-        buckets = 3
+    elif uses_log or world == 1:
+        # the update log and the asynchronous shards take the whole gradient at the end of the pass
+        # (short-circuiting needs no segment boundaries: every kernel checks the abort word itself)
+        buckets = 1
     else:
         from ..models.lenet import lenet_param_specs
         from ..models.resnet import resnet_param_specs
@@ -173,8 +176,6 @@ def train(flags, model: str) -> Dict:
 
         specs = lenet_param_specs() if model == "lenet" else resnet_param_specs(flags.num_residual_blocks)
         buckets = default_grad_buckets(sum(sp.numel for sp in specs))
-    if not (world > 1 or strategy_needs_segments):
-        buckets = 1
     replica = make_replica(
         model, batch_size, device, num_residual_blocks=flags.num_residual_blocks, optimizer=flags.optimizer,
         momentum=flags.momentum, weight_decay=flags.weight_decay if flags.optimizer == "momentum" else 0.0,

@@ -195,7 +195,6 @@ class HipReplica(ReplicaBase):
         self.arena.initialize(seed)
         self.stream = torch.cuda.Stream()
         self._eval_steps = {}
-        self._event = torch.cuda.Event()
         self.ctl_block = 0
         self.step = None
         self.use_graph = False
@@ -247,6 +246,11 @@ class HipReplica(ReplicaBase):
             self.step.load_batch(x.to(self.device, non_blocking=True), y.to(self.device, non_blocking=True))
 
     def forward_backward(self, on_bucket: BucketFn = None, should_abort: AbortFn = None) -> bool:
+        """Enqueues forward + backward, segment by segment (a segment ends where a gradient bucket is
+        final). Short-circuiting is not a host decision here: a replica built with `abortable=True`
+        records every kernel with an abort guard that reads the update log's words on the device, so
+        `should_abort` is not consulted and the host never waits for the GPU to find out how far the
+        pass got. Always returns True."""
         st = self.step
         self.last_aborted = False
         nseg = st.num_segments
@@ -254,24 +258,8 @@ class HipReplica(ReplicaBase):
             st.set_step_counter(self.updates_applied)
             for i in range(nseg - 1):
                 self._run_segment(i)
-                lo, hi = st.bucket_ranges[i]
-                if should_abort is not None and i < nseg - 2:
-                    # The host runs ahead of the GPU: wait for the segment before polling, so
-                    # the decision reflects how far backward really is.
-                    self._event.record(self.stream)
-                    self._event.synchronize()
-                    if should_abort():
-                        self.last_aborted = True
-                        for j in range(i + 1, nseg - 1):
-                            l2, h2 = st.bucket_ranges[j]
-                            st.zero_grad_range(l2, h2)
-                        if on_bucket is not None:
-                            on_bucket(lo, hi)
-                            for j in range(i + 1, nseg - 1):
-                                on_bucket(*st.bucket_ranges[j])
-                        return False
                 if on_bucket is not None:
-                    on_bucket(lo, hi)
+                    on_bucket(*st.bucket_ranges[i])
         return True
 
     def _run_segment(self, seg: int) -> None:

@@ -283,7 +283,7 @@ def test_a_killed_worker_is_noticed_by_name(tmp_path, mode):
     if mode == "sync":
         assert all(rc == 3 for rc in rcs), rcs                      # stopped by the watchdog, not by a collective timeout
         assert took < 30, took
-        assert all("the job cannot continue" in out[r] for r in (0, 1))
+        assert all("the job cannot continue" in out[r] for r in (0, 1))   # own verdict, or the faster worker's
     else:
         assert rcs == [0, 0], (rcs, out[0][-1500:])
         assert all("continuing without it" in out[r] for r in (0, 1))
