@@ -345,12 +345,12 @@ __global__ __launch_bounds__(256) void ulog_step_kernel(UlogArgs a) {
     acquire_fence();
 
     // gather the owners' shards, optimizer fused
-    int owner_rank[kUlogMaxPeers];
+    // rank of the k-th owner, four bits each (an indexed local array would live in scratch memory)
+    unsigned owner_of = 0;
     {
       int k = 0;
       for (int p = 0; p < kUlogMaxPeers; ++p)
-        if ((r.owners >> p) & 1u) owner_rank[k++] = p;
-      for (; k < kUlogMaxPeers; ++k) owner_rank[k] = a.rank;
+        if ((r.owners >> p) & 1u) owner_of |= (unsigned)p << (4 * k++);
     }
     const long long t = version + 1;
     const double lr = (double)a.lr0 * pow((double)a.decay, (double)(version / (a.decay_steps > 0 ? a.decay_steps : 1)));
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void ulog_step_kernel(UlogArgs a) {
       floatx4* v4 = reinterpret_cast<floatx4*>(a.v);
       for (long long i = gtid; i < n4; i += gstride) {
         const int k = (int)(i / chunk4);
-        const floatx4 g = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(a.red[owner_rank[k]]) + (long long)slot * n4 + i);
+        const floatx4 g = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(a.red[(owner_of >> (4 * k)) & 15u]) + (long long)slot * n4 + i);
         floatx4 p = p4[i], m = m4[i], v = v4[i];
         adam_update4(p, m, v, g, r.scale, lr_t, a.beta1, a.beta2, a.eps);
         p4[i] = p;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void ulog_step_kernel(UlogArgs a) {
     } else {
       for (long long i = gtid; i < n4; i += gstride) {
         const int k = (int)(i / chunk4);
-        const floatx4 g = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(a.red[owner_rank[k]]) + (long long)slot * n4 + i);
+        const floatx4 g = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(a.red[(owner_of >> (4 * k)) & 15u]) + (long long)slot * n4 + i);
         floatx4 p = p4[i], m = m4[i];
         momentum_update4(p, m, g, r.scale, (float)lr, a.momentum, a.weight_decay);
         p4[i] = p;
