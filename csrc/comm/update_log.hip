@@ -71,10 +71,22 @@ __device__ __forceinline__ int read_hist(u64* own, long long u, Rec& r) {
   return 1;
 }
 
-__device__ __forceinline__ bool all_ready(u64* own, long long u, unsigned owners) {
+// A ready word is (u + 1) in its low bits; a stand-in for a dead owner adds its own rank + 1 above
+// kReadyHolderShift: that is whose ring holds the shard.
+constexpr int kReadyHolderShift = 48;
+constexpr u64 kReadyUpdateMask = (1ull << kReadyHolderShift) - 1;
+
+// Owners of update u whose reduced shard is not published yet.
+__device__ __forceinline__ unsigned unready_owners(u64* own, long long u, unsigned owners) {
   const int slot = (int)(u % kUlogRing);
+  unsigned missing = 0;
   for (int p = 0; p < kUlogMaxPeers; ++p)
-    if (((owners >> p) & 1u) && ld(W(own, UW_READY + slot * kUlogMaxPeers + p)) < (u64)(u + 1)) return false;
+    if (((owners >> p) & 1u) && (ld(W(own, UW_READY + slot * kUlogMaxPeers + p)) & kReadyUpdateMask) < (u64)(u + 1)) missing |= 1u << p;
+  return missing;
+}
+
+__device__ __forceinline__ bool all_ready(u64* own, long long u, unsigned owners) {
+  if (unready_owners(own, u, owners)) return false;
   acquire_fence();
   return true;
 }
@@ -325,33 +337,85 @@ __global__ __launch_bounds__(256) void ulog_step_kernel(UlogArgs a) {
         out[i] = acc;
       }
     }
-    u64 ok = leader_step(lc, &s_payload, [&]() -> u64 {
-      if (owner)
-        for (int p = 0; p < a.world; ++p) st_rel(W(a.ctl[p], UW_READY + slot * kUlogMaxPeers + a.rank), (u64)(version + 1));
-      const long long t0 = wall_clock64();
-      while (!all_ready(own, version, r.owners)) {
-        if (wall_clock64() - t0 > a.timeout_ticks) {
-          raise_error(own, UE_READY);
-          return kActError;
+    // publish the own shard, then wait for every owner's. An owner the watchdog has given up on will
+    // never publish: the lowest-ranked live contributor stands in for it - it sums the dead owner's
+    // shard into its own ring (peer memory outlives its process for as long as it is mapped here)
+    // and publishes the ready word in the dead owner's name, tagged with where the shard lives.
+    bool published = !owner;
+    for (;;) {
+      const u64 verdict = leader_step(lc, &s_payload, [&]() -> u64 {
+        if (!published)
+          for (int p = 0; p < a.world; ++p) st_rel(W(a.ctl[p], UW_READY + slot * kUlogMaxPeers + a.rank), (u64)(version + 1));
+        const long long t0 = wall_clock64();
+        for (;;) {
+          const unsigned missing = unready_owners(own, version, r.owners);
+          if (!missing) break;
+          const unsigned dead = (unsigned)ld(W(own, UW_DEAD));
+          const unsigned live_contrib = r.mask & ~dead;
+          if ((missing & dead) && live_contrib && (live_contrib & (0u - live_contrib)) == (1u << a.rank))
+            return kActOk + 1 + (u64)(missing & dead);   // this replica stands in for them
+          if (wall_clock64() - t0 > a.timeout_ticks) {
+            raise_error(own, UE_READY);
+            return kActError;
+          }
+          nap();
         }
-        nap();
+        acquire_fence();
+        return kActOk;
+      });
+      published = true;
+      if (verdict == kActOk) break;
+      if (verdict == kActError || verdict < kActOk) {
+        act = kActError;
+        break;
       }
-      return kActOk;
-    });
-    if (ok != kActOk) {
-      act = kActError;
-      break;
+      const unsigned stand_in = (unsigned)(verdict - kActOk - 1);
+      floatx4* out = reinterpret_cast<floatx4*>(a.red[a.rank]) + (long long)slot * n4;
+      for (int d = 0; d < kUlogMaxPeers; ++d) {
+        if (!((stand_in >> d) & 1u)) continue;
+        const int idx = __popc(r.owners & ((1u << d) - 1u));
+        const long long lo = idx * chunk4;
+        const long long hi = lo + chunk4 < n4 ? lo + chunk4 : n4;
+        for (long long i = lo + gtid; i < hi; i += gstride) {
+          floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+          for (int q = 0; q < a.world; ++q)
+            if ((r.mask >> q) & 1u) acc += __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(a.stage[q]) + i);
+          out[i] = acc;
+        }
+      }
+      const u64 pub = leader_step(lc, &s_payload, [&]() -> u64 {
+        for (int d = 0; d < kUlogMaxPeers; ++d)
+          if ((stand_in >> d) & 1u)
+            for (int p = 0; p < a.world; ++p)
+              if (!(((unsigned)ld(W(own, UW_DEAD)) >> p) & 1u))
+                st_rel(W(a.ctl[p], UW_READY + slot * kUlogMaxPeers + d), (u64)(version + 1) | ((u64)(a.rank + 1) << kReadyHolderShift));
+        return kActOk;
+      });
+      if (pub != kActOk) {
+        act = kActError;
+        break;
+      }
     }
+    if (act == kActError) break;
     acquire_fence();
 
-    // gather the owners' shards, optimizer fused
-    // rank of the k-th owner, four bits each (an indexed local array would live in scratch memory)
-    unsigned owner_of = 0;
+    // gather the owners' shards, optimizer fused. holder_of: the rank whose ring holds the k-th
+    // owner's shard (the owner itself, or its stand-in), four bits each - an indexed local array
+    // would live in scratch memory
+    unsigned holder_of = 0;
     {
       int k = 0;
       for (int p = 0; p < kUlogMaxPeers; ++p)
-        if ((r.owners >> p) & 1u) owner_of |= (unsigned)p << (4 * k++);
+        if ((r.owners >> p) & 1u) {
+          const u64 word = ld(W(own, UW_READY + slot * kUlogMaxPeers + p));
+          const unsigned holder = (word >> kReadyHolderShift) ? (unsigned)(word >> kReadyHolderShift) - 1u : (unsigned)p;
+          holder_of |= holder << (4 * k++);
+        }
     }
+    auto reduced = [&](long long i) -> floatx4 {
+      const unsigned o = (holder_of >> (4 * (int)(i / chunk4))) & 15u;
+      return __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(a.red[o]) + (long long)slot * n4 + i);
+    };
     const long long t = version + 1;
     const double lr = (double)a.lr0 * pow((double)a.decay, (double)(version / (a.decay_steps > 0 ? a.decay_steps : 1)));
     floatx4* p4 = reinterpret_cast<floatx4*>(a.p);
@@ -360,8 +424,7 @@ __global__ __launch_bounds__(256) void ulog_step_kernel(UlogArgs a) {
       const float lr_t = (float)(lr * sqrt(1.0 - pow((double)a.beta2, (double)t)) / (1.0 - pow((double)a.beta1, (double)t)));
       floatx4* v4 = reinterpret_cast<floatx4*>(a.v);
       for (long long i = gtid; i < n4; i += gstride) {
-        const int k = (int)(i / chunk4);
-        const floatx4 g = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(a.red[(owner_of >> (4 * k)) & 15u]) + (long long)slot * n4 + i);
+        const floatx4 g = reduced(i);
         floatx4 p = p4[i], m = m4[i], v = v4[i];
         adam_update4(p, m, v, g, r.scale, lr_t, a.beta1, a.beta2, a.eps);
         p4[i] = p;
@@ -370,8 +433,7 @@ __global__ __launch_bounds__(256) void ulog_step_kernel(UlogArgs a) {
       }
     } else {
       for (long long i = gtid; i < n4; i += gstride) {
-        const int k = (int)(i / chunk4);
-        const floatx4 g = __builtin_nontemporal_load(reinterpret_cast<const floatx4*>(a.red[(owner_of >> (4 * k)) & 15u]) + (long long)slot * n4 + i);
+        const floatx4 g = reduced(i);
         floatx4 p = p4[i], m = m4[i];
         momentum_update4(p, m, g, r.scale, (float)lr, a.momentum, a.weight_decay);
         p4[i] = p;

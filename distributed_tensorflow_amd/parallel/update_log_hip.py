@@ -82,6 +82,7 @@ class DeviceUpdateLog:
         self._closed = False
         self.stream = replica.stream
         self.close_stream: Optional[torch.cuda.Stream] = None
+        self._ctl_stream: Optional[torch.cuda.Stream] = None
         dev = replica.device
         # control block: the replica's own if its step program short-circuits on it
         self._own_ctl = getattr(replica, "ctl_block", 0) or alloc_control_block()
@@ -244,8 +245,15 @@ class DeviceUpdateLog:
         return int(self._close_np[0]) - 1
 
     def mark_dead(self, rank: int) -> None:
-        """Stops waiting for `rank` in the back-pressure (the watchdog gave up on it)."""
-        nv.hip().ulog_mark_dead(self._own_ctl, 1 << rank, self.stream.cuda_stream)
+        """The watchdog gave up on `rank`: the kernels stop waiting for it in the back-pressure, and
+        the shards it owned in updates it had joined are summed by a stand-in. Called from the
+        watchdog's thread; the one-thread kernel runs on a stream of its own, because the training
+        stream may be occupied by a launch that is waiting for exactly this."""
+        with torch.cuda.device(self._device):
+            if self._ctl_stream is None:
+                self._ctl_stream = torch.cuda.Stream()
+            nv.hip().ulog_mark_dead(self._own_ctl, 1 << rank, self._ctl_stream.cuda_stream)
+            self._ctl_stream.synchronize()
 
     # ---------------------------------------------------------------------------------------------
     def finish(self, final_version: Optional[int] = None, collective: bool = True) -> None:

@@ -241,3 +241,49 @@ def test_driver_runs_the_straggler_policies_on_the_device_update_log(tmp_path, m
     if mode == "backup":
         by_rank = {r["rank"]: r for r in results}
         assert by_rank[1]["excluded_steps"] > by_rank[0]["excluded_steps"]
+
+
+def test_backup_workers_go_on_when_a_gpu_worker_is_killed(tmp_path):
+    """Three workers share GPU 0 under backup workers (2 of 3); worker 2 is SIGKILLed mid-run. The
+    survivors' watchdogs name it, take it out of the update log's back-pressure (and stand in for
+    any shard it owned), and both reach max_steps."""
+    import signal
+
+    from distributed_tensorflow_amd.launch import free_port, rank_environment
+
+    d = str(tmp_path)
+    port = free_port()
+    procs, logs = [], []
+    for r in range(3):
+        env = rank_environment(r, 3, port, 1, dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        logf = open(os.path.join(d, f"rank{r}.log"), "w")
+        logs.append(logf)
+        procs.append(subprocess.Popen(
+            [sys.executable, "DistributedResNet/src/resnet_distributed_train.py", "--synthetic_data", "--batch_size=32",
+             "--num_residual_blocks=1", "--max_steps=400", f"--train_dir={d}", "--initial_learning_rate=0.001",
+             "--comm_backend=gloo", "--save_interval_secs=100000", "--liveness_timeout_s=2", "--inject_straggler_ms=10",
+             "--inject_straggler_ranks=0,1,2", "--backup_worker_method=true", "--num_replicas_to_aggregate=2"],
+            stdout=logf, stderr=subprocess.STDOUT, env=env, cwd=ROOT))
+    try:
+        deadline = time.time() + 120
+        seen = False
+        while time.time() < deadline and not seen:
+            steps = [int(m.group(1)) for m in (re.search(r"step (\d+), loss = ", l) for l in open(os.path.join(d, "rank2.log"))) if m]
+            seen = bool(steps) and steps[-1] >= 20
+            time.sleep(0.1)
+        assert seen, open(os.path.join(d, "rank2.log")).read()[-2000:]
+        procs[2].send_signal(signal.SIGKILL)
+        rcs = [procs[r].wait(timeout=200) for r in (0, 1)]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for f in logs:
+            f.close()
+    out = [open(os.path.join(d, f"rank{r}.log")).read() for r in range(2)]
+    assert rcs == [0, 0], (rcs, out[0][-2500:], out[1][-2500:])
+    assert all("worker 2 has been silent" in o and "continuing without it" in o for o in out)
+    import json
+
+    results = [json.loads(l.split("RESULT ", 1)[1]) for o in out for l in o.splitlines() if "RESULT {" in l]
+    assert len(results) == 2 and all(r["global_step"] > 400 and r["dead_workers"] == [2] for r in results), results
