@@ -144,6 +144,20 @@ def train(flags, model: str) -> Dict:
 
     # ---- control board (single-node control plane)
     needs_board = world > 1
+    # The board is POSIX shared memory, and the update log / asynchronous shards map peers' HBM:
+    # both end at the node. Plain synchronous training only needs the process group, so it also
+    # runs over several nodes (RCCL across them), without the board's extras (liveness watchdog,
+    # worker-time telemetry).
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world > 1 and local_world < world:
+        needs_one_node = [f for f in ("interval_method", "soft_kill_method", "backup_worker_method", "weighted_grads_method",
+                                      "async_method", "worker_times_cdf_method", "reduce_scatter") if getattr(flags, f, False)]
+        if needs_one_node:
+            raise ValueError(f"{world} ranks over nodes of {local_world}: --{needs_one_node[0]} coordinates through shared memory "
+                             "and peer-mapped HBM and runs within one node; only plain synchronous training spans nodes")
+        log.info("Worker %d: %d ranks span several nodes (%d per node): synchronous all-reduce over the process group, "
+                 "no shared-memory control board", rank, world, local_world)
+        needs_board = False
     board = None
     if needs_board:
         name = flags.board_name or control_plane.board_name_for(train_dir, task.master_port)
@@ -235,6 +249,8 @@ def train(flags, model: str) -> Dict:
         log.info("Worker %d: aggregation policy %s over %d replicas (aggregate %d)", rank, strategy.name, world, num_replicas_to_aggregate)
 
     timeout_client, timeout_server = control_plane.launch_manager(board, rank, world, flags.collective_timeout_s)
+    if board is None and world > 1:
+        comm.barrier()      # the ready barrier, through the process group
     watchdog = None
     if board is not None and world > 1:
         silence = flags.liveness_timeout_s if flags.liveness_timeout_s > 0 else flags.collective_timeout_s / 4.0

@@ -289,3 +289,33 @@ def test_a_killed_worker_is_noticed_by_name(tmp_path, mode):
         assert all("continuing without it" in out[r] for r in (0, 1))
         steps = [int(m.group(2)) for m in (TRAIN_RE.match(l) for l in out[0].splitlines()) if m]
         assert steps[-1] >= 120
+
+
+def test_plain_sync_spans_nodes_without_the_board_and_policies_refuse(tmp_path):
+    """LOCAL_WORLD_SIZE < WORLD_SIZE means the ranks sit on several nodes: full sync runs through
+    the process group alone; a policy that needs shared memory says so and stops."""
+    from distributed_tensorflow_amd.launch import free_port, rank_environment
+
+    def run(extra, sub):
+        d = str(tmp_path / sub)
+        os.makedirs(d)
+        port = free_port()
+        procs = []
+        for r in range(2):
+            env = rank_environment(r, 2, port, 0, dict(os.environ, OMP_NUM_THREADS="1"))
+            env["LOCAL_WORLD_SIZE"] = "1"
+            env["LOCAL_RANK"] = "0"
+            procs.append(subprocess.Popen(
+                [sys.executable, "DistributedLeNet/src/mnist_distributed_train.py", "--synthetic_data", "--device=cpu", "--batch_size=8",
+                 f"--train_dir={d}", "--max_steps=5", "--save_interval_secs=100000"] + extra,
+                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=ROOT))
+        outs = [p.communicate(timeout=200)[0] for p in procs]
+        return [p.returncode for p in procs], outs
+
+    rcs, outs = run([], "sync")
+    assert rcs == [0, 0], outs[0][-2000:]
+    assert all("span several nodes" in o for o in outs)
+    steps = [int(m.group(2)) for m in (TRAIN_RE.match(l) for l in outs[1].splitlines()) if m]
+    assert steps == list(range(1, 6))
+    rcs, outs = run(["--backup_worker_method=true", "--num_replicas_to_aggregate=1"], "backup")
+    assert all(rc != 0 for rc in rcs) and all("runs within one node" in o for o in outs)
