@@ -3,6 +3,7 @@ by their original class names."""
 from .flat import FlatAdam, FlatMomentumSGD  # noqa: F401
 from .sync_replicas import (  # noqa: F401
     BackupOptimizer,
+    ChiefQueueRunner,
     SoftKillOptimizer,
     SyncReplicasOptimizer,
     SyncReplicasOptimizerV2,
