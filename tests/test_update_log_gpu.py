@@ -295,5 +295,8 @@ def test_short_circuit_in_the_middle_of_backward_leaves_zeros_beyond_the_cut():
     conv_full = [e for seg in full[1:] for e in seg if "conv" in e[0]]
     conv_cut = [e for seg in cut for e in seg if "conv" in e[0]]
     assert len(conv_cut) == len(conv_full) >= 10                               # one abort point per kernel
-    assert max(e[4] for e in conv_cut) < 15.0, sorted(e[4] for e in conv_cut)[-3:]   # microseconds
+    # microseconds between the two timing events around a launch: a cut kernel is launch latency only
+    # (an occasional event pair is slow by itself, hence the median and a loose bound on the worst)
+    times = sorted(e[4] for e in conv_cut)
+    assert times[len(times) // 2] < 10.0 and times[-1] < 60.0, times[-3:]
     assert sum(e[4] for e in conv_cut) < 0.3 * sum(e[4] for e in conv_full)
