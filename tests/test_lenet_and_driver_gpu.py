@@ -145,7 +145,12 @@ def test_two_gpu_replicas_stay_identical(mode):
         # updates follow the timer, not the iteration count; both replicas end on the same one
         assert out[0]["updates"] == out[1]["updates"] >= 2
         return
-    assert all(o["updates"] == 6 for o in out)
+    if mode == "backup":
+        # one gradient per update (M = 1 of 2): every accepted gradient is an update of its own, so six
+        # iterations per replica make between 6 and 12 updates, the same number on both
+        assert out[0]["updates"] == out[1]["updates"] and 6 <= out[0]["updates"] <= 12
+    else:
+        assert all(o["updates"] == 6 for o in out)
     if mode in ("backup", "soft_kill", "weighted"):
         # the update may come from the OTHER replica's batch only, so a replica's own loss need not fall
         assert all(l == l and l < 10 for o in out for l in o["losses"])
