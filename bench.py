@@ -92,7 +92,9 @@ def bench_policy(args) -> None:
     if args.mode == "async":
         from distributed_tensorflow_amd.parallel.async_ps import AsyncParameterShards
 
-        shards = AsyncParameterShards(replica, comm, board, args.staleness, name + "_ps", args.lr)
+        tau = args.staleness if args.staleness >= 0 else 2 * world
+        detail["staleness_bound"] = tau
+        shards = AsyncParameterShards(replica, comm, board, tau, name + "_ps", args.lr)
         shards.read_loss_every_step = False   # the host only enqueues: pull, step, push and the owners' applies are kernels
         step_fn = lambda i: shards.step()   # noqa: E731
     else:
@@ -243,7 +245,9 @@ def main() -> None:
                          "sharded = reduce-scatter + per-shard optimizer + all-gather; backup = mean of the first "
                          "--aggregate gradients (masked all-reduce); async = staleness-bounded parameter shards")
     ap.add_argument("--aggregate", type=int, default=0, help="backup mode: gradients per update (default N-1)")
-    ap.add_argument("--staleness", type=int, default=4, help="async mode: staleness bound")
+    ap.add_argument("--staleness", type=int, default=-1,
+                    help="async mode: staleness bound in shard versions (-1: twice the number of ranks - every rank pushes to "
+                         "every shard once per iteration, so a version is already `ranks` behind after one round)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="allow more ranks than distinct GPUs (rehearsal of the multi-rank path on one GPU; needs --backend gloo, "
                          "RCCL refuses two ranks on one device). The JSON then reports n_gpus = distinct GPUs")

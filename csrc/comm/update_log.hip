@@ -173,7 +173,7 @@ __device__ bool take_back(const UlogArgs& a, long long e, int count) {
 __device__ __forceinline__ void bump_stat(u64* own, int which, u64 by) { st(W(own, UW_STATS + which), ld(W(own, UW_STATS + which)) + by); }
 
 // ---------------------------------------------------------------------------------------------------
-// ulog_begin: one thread. D0 = seq<<32 | count<<8 | dropped<<2 | stage op (0 none, 1 copy, 2 add).
+// ulog_begin: one thread. D0 = seq<<32 | count<<8 | withdrawn<<3 | dropped<<2 | stage op (0 none, 1 copy, 2 add).
 __global__ void ulog_begin_kernel(UlogArgs a) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   u64* own = a.ctl[a.rank];
@@ -181,7 +181,7 @@ __global__ void ulog_begin_kernel(UlogArgs a) {
   st(W(own, UW_SEQ), seq);
   st(W(own, UW_COUNTER), 0);
   const long long e = (long long)ld(W(own, UW_VERSION));
-  u64 op = 0, count = 1, dropped = 0;
+  u64 op = 0, count = 1, dropped = 0, withdrawn = 0;
   if (ld(W(own, UW_ERROR)) == 0) {
     const long long t0 = wall_clock64();
     if (a.mode == ULOG_CONTRIBUTE) {
@@ -223,14 +223,15 @@ __global__ void ulog_begin_kernel(UlogArgs a) {
         const long long open_now = open_u(ld_acq(W(a.ctl[0], UW_OPEN)));
         if ((a.max_staleness >= 0 && open_now - e > a.max_staleness) || open_now >= a.max_version ||
             min_applied(a) < open_now - kUlogRing + 1) {
+          withdrawn = op == 2 ? 1 : 0;
           op = 0;
-          dropped = open_now < a.max_version ? 1 : 0;
+          dropped = (open_now < a.max_version || withdrawn) ? 1 : 0;
         }
       }
       if (!keep_pending) st(W(own, UW_PENDING), 0);
     }
   }
-  st(W(own, UW_D0), (seq << 32) | (count << 8) | (dropped << 2) | op);
+  st(W(own, UW_D0), (seq << 32) | (count << 8) | (withdrawn << 3) | (dropped << 2) | op);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -299,7 +300,8 @@ __global__ __launch_bounds__(256) void ulog_step_kernel(UlogArgs a) {
         return kActError;
       }
       if (status == 0) {
-        bump_stat(own, US_ACCEPTED, (u64)add);
+        // a staged sum that was withdrawn and re-added with one more gradient was counted before
+        bump_stat(own, US_ACCEPTED, op == 2 ? 1ull : (u64)add);
         last_flags = 1ull | (closed ? 2ull : 0ull) | ((u64)order << 8);
         if (any)
           st(W(own, UW_PENDING), ((u64)(open_now + 1) << 16) | (u64)add);
@@ -310,7 +312,14 @@ __global__ __launch_bounds__(256) void ulog_step_kernel(UlogArgs a) {
         if (status == 2) wait_u = version;   // the closer is publishing this very update: a short wait
       }
     } else {
-      if (d0 & 4) bump_stat(own, US_DROPPED, 1);
+      if (d0 & 4) {
+        if (d0 & 8) {   // the withdrawn sum went down with the new gradient: they no longer count as accepted
+          st(W(own, UW_STATS + US_ACCEPTED), ld(W(own, UW_STATS + US_ACCEPTED)) - (u64)(add - 1));
+          bump_stat(own, US_DROPPED, (u64)add);
+        } else {
+          bump_stat(own, US_DROPPED, 1);
+        }
+      }
       if (a.mode == ULOG_SKIP) wait_u = version;
     }
     return next_action(a, own, version, wait_u);

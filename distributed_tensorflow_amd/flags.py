@@ -232,7 +232,9 @@ def define_extension_flags() -> None:
     DEFINE_boolean("async_method", False, "Asynchronous SGD over staleness-bounded parameter shards")
     DEFINE_integer("interval_max_staleness", -1, "Interval mode: drop a gradient computed on parameters more than this many "
                    "updates old (-1: accept any, the gradient counts for the window that is open when it is pushed, like the reference)")
-    DEFINE_integer("staleness_bound", 4, "Async mode: gradients older than this many updates are dropped")
+    DEFINE_integer("staleness_bound", -1, "Async mode: gradients older than this many shard versions are dropped "
+                   "(0: only fresh ones, the accumulator's rule; -1: twice the number of workers - every worker "
+                   "pushes to every shard once per iteration, so a version is a round old after `workers` pushes)")
     DEFINE_boolean("weighted_grads_method", False, "Least-squares weighted gradient aggregation with simulated worker kills")
     DEFINE_integer("grad_buckets", 0, "Gradient all-reduce buckets overlapped with the backward pass (0: three for the "
                    "straggler policies, which poll at bucket boundaries, else by gradient size)")

@@ -229,7 +229,7 @@ def train(flags, model: str) -> Dict:
         if board is None:
             board = control_plane.open_board(name + "_b", world, rank)
         shards = AsyncParameterShards(
-            replica, comm, board, flags.staleness_bound, name,
+            replica, comm, board, flags.staleness_bound if flags.staleness_bound >= 0 else 2 * world, name,
             lr_mod.StaircaseSchedule(flags.initial_learning_rate, decay_steps, flags.learning_rate_decay_factor),
         )
         board.set_global_step(global_step) if is_chief else None
