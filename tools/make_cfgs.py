@@ -79,12 +79,12 @@ def main() -> None:
     for b in (128, 1024):
         write(f"{le}/time_cdf_cfgs/8_gpus_batch_{b}_cdf",
               lenet(f"lenet_8_gpus_batch_{b}_cdf", "--worker_times_cdf_method=true ", batch_size=str(b), max_steps="500"))
-    write(f"{le}/8_gpus/8_gpus_async_tau4", lenet("lenet_8_gpus_async_tau4", "--async_method=true --staleness_bound=4 "))
+    write(f"{le}/8_gpus/8_gpus_async_tau16", lenet("lenet_8_gpus_async_tau16", "--async_method=true --staleness_bound=16 "))
     # ResNet: the reference's default (backup workers, all aggregated), straggler drop, sharded optimizer, large batch
     write(f"{re_}/8_gpus/resnet20_sync", resnet("resnet20_8_gpus_sync", ""))
     write(f"{re_}/8_gpus/resnet32_backup_7_of_8", resnet("resnet32_8_gpus_backup_7_of_8", "--backup_worker_method=true ", n=5,
                                                           num_replicas_to_aggregate="7"))
-    write(f"{re_}/8_gpus/resnet32_async_tau4", resnet("resnet32_8_gpus_async_tau4", "--async_method=true --staleness_bound=4 ", n=5))
+    write(f"{re_}/8_gpus/resnet32_async_tau16", resnet("resnet32_8_gpus_async_tau16", "--async_method=true --staleness_bound=16 ", n=5))
     write(f"{re_}/8_gpus/resnet20_sharded_optimizer", resnet("resnet20_8_gpus_sharded", "--reduce_scatter=true "))
     write(f"{re_}/8_gpus/resnet20_p2p_allreduce", resnet("resnet20_8_gpus_p2p", "--allreduce_impl=p2p "))
     write(f"{re_}/8_gpus/resnet110_large_batch", resnet("resnet110_8_gpus_batch_1024", "--grad_buckets=4 ", n=18, batch_size="1024"))
