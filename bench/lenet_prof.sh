@@ -2,7 +2,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/lenet_prof
-timeout -k 10 150 rocprofv3 --kernel-trace -d $R/gpurun_out/lenet_prof -o lenet -- python3 $R/bench/lenet_trace.py 1024 > $R/gpurun_out/lenet_prof.log 2>&1
+timeout -k 10 150 rocprofv3 --kernel-trace -d $R/gpurun_out/lenet_prof -o lenet -- python3 $R/bench/lenet_trace.py ${1:-1024} > $R/gpurun_out/lenet_prof.log 2>&1
 cd $R
 DB=$(find gpurun_out/lenet_prof -name "*.db" | head -1)
 python3 - "$DB" > gpurun_out/lenet_stats.md <<'PY'

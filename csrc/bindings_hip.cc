@@ -214,6 +214,13 @@ PYBIND11_MODULE(_hip, m) {
     P(logits, const float); P(labels, const int); P(dlogits, float); P(loss, float); P(correct, int); V(B); V(K);
     softmax_xent(a, as_stream(stream));
   });
+  m.def("fc_head", [](const py::dict& d, uint64_t stream) {
+    FcHeadArgs a{};
+    P(h_raw, const float); P(b1, const float); P(w2, const float); P(b2, const float); P(labels, const int);
+    P(logits, float); P(loss, float); P(correct, int); P(dh, float); P(dw2, float); P(db2, float); P(db1, float);
+    V(B); V(H); V(K); V(keep_prob); V(seed); V(offset); P(offset_dev, const unsigned long long); V(max_blocks);
+    fc_head(a, as_stream(stream));
+  });
   m.def("top1_count", [](const py::dict& d, uint64_t stream) {
     Top1Args a{};
     P(logits, const float); P(labels, const int); P(correct, int); V(B); V(K);
@@ -403,7 +410,7 @@ PYBIND11_MODULE(_hip, m) {
   m.def("gemm_f32", [](const py::dict& d, uint64_t stream) {
     GemmArgs a{};
     P(A, const float); P(B, const float); P(C, float); P(bias, const float);
-    V(M); V(N); V(K); V(lda); V(ldb); V(ldc); V(trans_a); V(trans_b); V(relu); V(accumulate);
+    V(M); V(N); V(K); V(lda); V(ldb); V(ldc); V(trans_a); V(trans_b); V(relu); V(accumulate); V(variant); V(splits);
     gemm_f32(a, as_stream(stream));
   });
   m.def("col_sum", [](const py::dict& d, uint64_t stream) {

@@ -1,6 +1,7 @@
 // Memory-bound kernels: elementwise, pooling, dropout, small reductions, augmentation, and
 // the one-launch filter re-packer. All stream 16 bytes per lane where the layout allows.
 #include "ops.h"
+#include "philox.h"
 
 namespace dtf {
 namespace {
@@ -141,19 +142,6 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxPoolBwdArgs a) {
   }
 }
 
-// Philox-4x32-10 counter-based generator: element i uses counter (offset + i/4), lane i%4.
-__device__ __forceinline__ void philox_round(uint32_t (&ctr)[4], uint32_t k0, uint32_t k1) {
-  const uint64_t p0 = (uint64_t)0xD2511F53u * ctr[0];
-  const uint64_t p1 = (uint64_t)0xCD9E8D57u * ctr[2];
-  const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
-  const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-  const uint32_t c1 = ctr[1], c3 = ctr[3];
-  ctr[0] = hi1 ^ c1 ^ k0;
-  ctr[1] = lo1;
-  ctr[2] = hi0 ^ c3 ^ k1;
-  ctr[3] = lo0;
-}
-
 __global__ __launch_bounds__(256) void dropout_kernel(DropoutArgs a) {
   DTF_ABORT_GUARD(a);
   const long long n4 = (a.n + 3) >> 2;
@@ -161,19 +149,13 @@ __global__ __launch_bounds__(256) void dropout_kernel(DropoutArgs a) {
   const float inv_keep = 1.f / a.keep_prob;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const unsigned long long cidx = a.offset + (a.offset_dev ? *a.offset_dev : 0ull) + (unsigned long long)i;
-    uint32_t ctr[4] = {(uint32_t)cidx, (uint32_t)(cidx >> 32), 0u, 0u};
-    uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-      philox_round(ctr, k0, k1);
-      k0 += 0x9E3779B9u;
-      k1 += 0xBB67AE85u;
-    }
+    uint32_t ctr[4];
+    philox4x32_10(cidx, a.seed, ctr);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const long long j = i * 4 + e;
       if (j < a.n) {
-        const float u = (float)(ctr[e] >> 8) * (1.0f / 16777216.0f);  // [0,1)
+        const float u = philox_uniform(ctr[e]);
         a.y[j] = (u < a.keep_prob) ? a.x[j] * inv_keep : 0.f;
       }
     }

@@ -1,7 +1,7 @@
 // fp32 GEMM on the exact-fp32 matrix cores (fully connected layers of LeNet).
 //
-// C[M,N] = op(A)[M,K] * op(B)[K,N] (+ bias[N]) (ReLU). Two kernels: a 128x128 block tile for
-// large aligned problems (below) and the general one: 64x64 block tile, 32-deep k-step, four
+// C[M,N] = op(A)[M,K] * op(B)[K,N] (+ bias[N]) (ReLU). Vector-load tile kernels for aligned
+// problems (further down) and the general one: 64x64 block tile, 32-deep k-step, four
 // waves each owning a 32x32 quadrant as 2x2 MFMA 16x16x4 tiles. Both operand tiles are stored
 // k-contiguous in LDS ([row][k] and [col][k], rows padded by 4 floats) so that one
 // ds_read_b128 per operand feeds four MFMAs, using the same k-permutation as the conv kernels.
@@ -22,6 +22,7 @@ struct GemmKArgs {
   GemmArgs g;
   int k_per_split;
   int atomic_out;
+  int gx, gy, total;   // tile grid of the vector-load kernels (launched one-dimensional, see tile_of)
   AbortRef abort;
 };
 
@@ -123,39 +124,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmKArgs ka) {
       }
 }
 
-// ---- 128x128 block tile for the large fully connected products (every dimension and leading
-// dimension a multiple of 4). Four waves, each a 64x64 quadrant = 4x4 MFMA tiles (64 accumulator
-// registers): 8 operand fragments feed 64 MFMAs per 16 k, twice the ratio of the 64x64 kernel.
+// ---- Vector-load tiles for aligned problems (every dimension and leading dimension a multiple
+// of 4). Four waves in a 2x2 arrangement, each a (TM/2)x(TN/2) quadrant of 16x16 MFMA tiles.
 // Global loads are 16 bytes wide along whichever dimension is contiguous in memory, and an
 // operand is kept in LDS the way it is stored: k-contiguous operands ([row][k]) are read back
 // with one ds_read_b128 per fragment, row-contiguous ones ([k][row], the transposed forms) with
-// four conflict-free ds_read_b32 — no transposing scatter into LDS either way.
+// four conflict-free ds_read_b32 - no transposing scatter into LDS either way.
+//
+// Two shapes are in use:
+//   128x128, 32 deep   large products: 8 operand fragments feed 64 MFMAs per 16 k.
+//   64x64, 128 deep    batch-sized products split along k. A workgroup of such a product walks a
+//                      few hundred k: with a 32-deep step that is a dozen round trips to memory
+//                      with one step of loads in flight each, and the kernel's time is those
+//                      round trips, not its arithmetic. A 128-deep step keeps four times the
+//                      bytes in flight per round trip.
 constexpr int TM = 128, TN = 128, TK = 32;
-constexpr int LDK = TK + 4;    // [row][k] layout: row stride
-constexpr int LDR = TM + 4;    // [k][row] layout: k stride
 
-template <bool KC>   // KC: the operand is k-contiguous in memory (ld = row stride), else row-contiguous (ld = k stride)
-struct Tile128 {
-  static constexpr int FLOATS = KC ? TM * LDK : TK * LDR;
-  // 1024 float4 per tile and k-step, 4 per thread
-  __device__ static void fetch(const float* __restrict__ src, int ld, int row0, int rows, int k0, int k_end, int tid, float4 (&r)[4]) {
+template <int ROWS, int DEPTH, bool KC>   // KC: the operand is k-contiguous in memory (ld = row stride), else row-contiguous (ld = k stride)
+struct OperandTile {
+  static constexpr int LDK = DEPTH + 4;   // [row][k] layout: row stride
+  static constexpr int LDR = ROWS + 4;    // [k][row] layout: k stride
+  static constexpr int FLOATS = KC ? ROWS * LDK : DEPTH * LDR;
+  static constexpr int NV = ROWS * DEPTH / 4 / 256;   // float4 per thread and k-step
+  static_assert(ROWS * DEPTH % 1024 == 0, "a k-step of an operand is a whole number of float4 per thread");
+  __device__ static void fetch(const float* __restrict__ src, int ld, int row0, int rows, int k0, int k_end, int tid, float4 (&r)[NV]) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NV; ++it) {
       const int e = tid + it * 256;
       int row, k;
-      if (KC) { k = (e & 7) * 4; row = e >> 3; } else { row = (e & 31) * 4; k = e >> 5; }
+      if (KC) { k = (e % (DEPTH / 4)) * 4; row = e / (DEPTH / 4); } else { row = (e % (ROWS / 4)) * 4; k = e / (ROWS / 4); }
       const int gr = row0 + row, gk = k0 + k;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gr < rows && gk < k_end) v = *reinterpret_cast<const float4*>(KC ? src + (size_t)gr * ld + gk : src + (size_t)gk * ld + gr);
       r[it] = v;
     }
   }
-  __device__ static void commit(float* lds, int tid, const float4 (&r)[4]) {
+  __device__ static void commit(float* lds, int tid, const float4 (&r)[NV]) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NV; ++it) {
       const int e = tid + it * 256;
-      if (KC) *reinterpret_cast<float4*>(lds + (e >> 3) * LDK + (e & 7) * 4) = r[it];
-      else *reinterpret_cast<float4*>(lds + (e >> 5) * LDR + (e & 31) * 4) = r[it];
+      if (KC) *reinterpret_cast<float4*>(lds + (e / (DEPTH / 4)) * LDK + (e % (DEPTH / 4)) * 4) = r[it];
+      else *reinterpret_cast<float4*>(lds + (e / (ROWS / 4)) * LDR + (e % (ROWS / 4)) * 4) = r[it];
     }
   }
   // values k = kg*16 + 4q + (0..3) of row `row`
@@ -168,62 +177,74 @@ struct Tile128 {
   }
 };
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm128_kernel(GemmKArgs ka) {
+template <int TM_, int TN_, int TK_, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmKArgs ka) {
   DTF_ABORT_GUARD(ka);
   const GemmArgs& a = ka.g;
-  using TileA = Tile128<!TA>;   // A [M,K] row-major is k-contiguous; trans_a stores [K,M]
-  using TileB = Tile128<TB>;    // B [K,N] row-major is n-contiguous; trans_b stores [N,K]
+  using TileA = OperandTile<TM_, TK_, !TA>;   // A [M,K] row-major is k-contiguous; trans_a stores [K,M]
+  using TileB = OperandTile<TN_, TK_, TB>;    // B [K,N] row-major is n-contiguous; trans_b stores [N,K]
+  constexpr int MI = TM_ / 32, NJ = TN_ / 32;  // MFMA tiles per wave
   __shared__ __attribute__((aligned(16))) float As[TileA::FLOATS];
   __shared__ __attribute__((aligned(16))) float Bs[TileB::FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, l15 = lane & 15;
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-  const int k_begin = blockIdx.z * ka.k_per_split;
+  // Workgroups go to the eight XCDs round-robin by their linear id, and every XCD has its own L2.
+  // Work item t = (id % 8) * (items per XCD) + id / 8 gives each XCD one contiguous range of
+  // (split, row tile, column tile) with the column tile running fastest: the workgroups an XCD runs
+  // at a time share their A rows eight ways and their B columns across the row tiles, and over the
+  // whole kernel an XCD's L2 fetches about an eighth of the operands instead of nearly all of them.
+  const int per_xcd = (ka.total + 7) >> 3;
+  const int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (t >= ka.total) return;
+  const int tx = t % ka.gx, ty = (t / ka.gx) % ka.gy, tz = t / (ka.gx * ka.gy);
+  const int m0 = ty * TM_, n0 = tx * TN_;
+  const int k_begin = tz * ka.k_per_split;
   int k_end = k_begin + ka.k_per_split;
   if (k_end > a.K) k_end = a.K;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave >> 1) * (TM_ / 2), wn = (wave & 1) * (TN_ / 2);
 
-  floatx4 acc[4][4];
+  floatx4 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0, 0, 0, 0};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = floatx4{0, 0, 0, 0};
 
-  float4 ra[4], rb[4];
+  float4 ra[TileA::NV], rb[TileB::NV];
   if (k_begin < k_end) {
     TileA::fetch(a.A, a.lda, m0, a.M, k_begin, k_end, tid, ra);
     TileB::fetch(a.B, a.ldb, n0, a.N, k_begin, k_end, tid, rb);
   }
-  for (int k0 = k_begin; k0 < k_end; k0 += TK) {
+  for (int k0 = k_begin; k0 < k_end; k0 += TK_) {
     TileA::commit(As, tid, ra);
     TileB::commit(Bs, tid, rb);
     __syncthreads();
-    if (k0 + TK < k_end) {   // in flight during the MFMAs
-      TileA::fetch(a.A, a.lda, m0, a.M, k0 + TK, k_end, tid, ra);
-      TileB::fetch(a.B, a.ldb, n0, a.N, k0 + TK, k_end, tid, rb);
+    if (k0 + TK_ < k_end) {   // in flight during the MFMAs
+      TileA::fetch(a.A, a.lda, m0, a.M, k0 + TK_, k_end, tid, ra);
+      TileB::fetch(a.B, a.ldb, n0, a.N, k0 + TK_, k_end, tid, rb);
     }
+    const int k_left = k_end - k0;
 #pragma unroll
-    for (int kg = 0; kg < TK / 16; ++kg) {
-      floatx4 av[4], bv[4];
+    for (int kg = 0; kg < TK_ / 16; ++kg) {
+      if (kg * 16 >= k_left) break;   // the last step of a split may be short: its empty groups hold zeros
+      floatx4 av[MI], bv[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) av[i] = TileA::frag(As, wm + i * 16 + l15, kg, q);
+      for (int i = 0; i < MI; ++i) av[i] = TileA::frag(As, wm + i * 16 + l15, kg, q);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bv[j] = TileB::frag(Bs, wn + j * 16 + l15, kg, q);
+      for (int j = 0; j < NJ; ++j) bv[j] = TileB::frag(Bs, wn + j * 16 + l15, kg, q);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = DTF_MFMA16(av[i][s], bv[j][s], acc[i][j]);
+          for (int j = 0; j < NJ; ++j) acc[i][j] = DTF_MFMA16(av[i][s], bv[j][s], acc[i][j]);
     }
     __syncthreads();
   }
 
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm + i * 16 + 4 * q + r;
@@ -240,6 +261,13 @@ __global__ __launch_bounds__(256) void gemm128_kernel(GemmKArgs ka) {
           *dst = v;
         }
       }
+}
+
+using GemmKernel = void (*)(GemmKArgs);
+template <int TM_, int TN_, int TK_>
+GemmKernel tile_kernel(bool ta, bool tb) {
+  return ta ? (tb ? gemm_tile_kernel<TM_, TN_, TK_, true, true> : gemm_tile_kernel<TM_, TN_, TK_, true, false>)
+            : (tb ? gemm_tile_kernel<TM_, TN_, TK_, false, true> : gemm_tile_kernel<TM_, TN_, TK_, false, false>);
 }
 
 struct BiasActArgs { float* C; const float* bias; int M, N, ldc, relu; AbortRef abort; };
@@ -260,23 +288,53 @@ __global__ __launch_bounds__(256) void bias_act_kernel(BiasActArgs a) {
 }  // namespace
 
 void gemm_f32(const GemmArgs& a, hipStream_t stream) {
-  // the large tile pays once there are enough of them to spread over the CUs with a modest k split
-  // (measured on the LeNet products: batch 1024 gains 25-35 %, batch 256 loses to the split-k overhead)
-  const int tiles128 = ceil_div(a.M, TM) * ceil_div(a.N, TN);
-  const bool big = ((tiles128 >= 32 && a.K >= 1024) || (tiles128 >= 160 && a.K >= 4 * TK)) && ((a.M | a.N | a.K | a.lda | a.ldb) & 3) == 0 &&
-                   (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0;
-  const int bm = big ? TM : BM, bn = big ? TN : BN;
+  const bool aligned = ((a.M | a.N | a.K | a.lda | a.ldb) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(a.B) & 15) == 0;
+  // variant (0 = choose here): 1 general 64x64x32, 2 128x128x32, 3 64x64x128, 4 64x128x64, 5 128x128x64, 6 64x64x64
+  // Measured on the fully connected products of the MNIST network (bench/gemm_sweep.py, batch 128
+  // to 2048): the 64x64 tile with a 64-deep step is the fastest or within 5 % of it on every one
+  // of them (20-30 % ahead of the 32-deep general kernel and, up to batch 2048, of the 128x128
+  // tile, which leaves most CUs without work at these sizes).
+  int variant = a.variant;
+  if (variant == 0) variant = ceil_div(a.M, TM) * ceil_div(a.N, TN) >= 512 ? 2 : 6;
+  if (!aligned) variant = 1;
+  int bm, bn, bk;
+  GemmKernel kernel;
+  switch (variant) {
+    case 2: bm = 128; bn = 128; bk = 32; kernel = tile_kernel<128, 128, 32>(a.trans_a, a.trans_b); break;
+    case 3: bm = 64; bn = 64; bk = 128; kernel = tile_kernel<64, 64, 128>(a.trans_a, a.trans_b); break;
+    case 4: bm = 64; bn = 128; bk = 64; kernel = tile_kernel<64, 128, 64>(a.trans_a, a.trans_b); break;
+    case 5: bm = 128; bn = 128; bk = 64; kernel = tile_kernel<128, 128, 64>(a.trans_a, a.trans_b); break;
+    case 6: bm = 64; bn = 64; bk = 64; kernel = tile_kernel<64, 64, 64>(a.trans_a, a.trans_b); break;
+    default: variant = 1; bm = BM; bn = BN; bk = BK; kernel = gemm_kernel; break;
+  }
   const int gx = ceil_div(a.N, bn), gy = ceil_div(a.M, bm);
   int splits = 1;
-  const int k_steps = ceil_div(a.K, BK);
-  while (gx * gy * splits < (big ? 200 : 256) && splits * 2 <= k_steps / 4 && splits < 32) splits *= 2;
+  if (a.splits > 0) {
+    splits = a.splits;
+  } else if (variant == 1) {
+    const int k_steps = ceil_div(a.K, BK);
+    while (gx * gy * splits < 256 && splits * 2 <= k_steps / 4 && splits < 32) splits *= 2;
+  } else {
+    // Split along k until about four workgroups per CU exist (they hide each other's memory round
+    // trips), while a split keeps at least three 64-deep steps' worth of k (192): below that the
+    // prologue, the epilogue and the atomics of a workgroup outweigh what the extra parallelism buys.
+    // A product that does not accumulate also pays for clearing its output first, which only a
+    // small output or a grid that would leave CUs idle is worth.
+    const long long out = (long long)a.M * a.N;
+    while (gx * gy * splits < 1024 && a.K / (splits * 2) >= 192 && out * splits * 2 <= (8ll << 20) &&
+           (a.accumulate || out <= 1200000 || gx * gy * splits < 256) && splits < 32)
+      splits *= 2;
+  }
   GemmKArgs ka;
   ka.g = a;
-  ka.k_per_split = ceil_div(k_steps, splits) * BK;
+  // a split starts on a multiple of 16 (whole MFMA k groups, 16-byte aligned rows); its last k-step may be short
+  ka.k_per_split = variant == 1 ? ceil_div(ceil_div(a.K, BK), splits) * BK : ceil_div(ceil_div(a.K, 16), splits) * 16;
+  splits = ceil_div(a.K, ka.k_per_split);
   ka.atomic_out = splits > 1;
-  auto kernel = !big ? gemm_kernel
-                     : a.trans_a ? (a.trans_b ? gemm128_kernel<true, true> : gemm128_kernel<true, false>)
-                                 : (a.trans_b ? gemm128_kernel<false, true> : gemm128_kernel<false, false>);
+  ka.gx = gx; ka.gy = gy; ka.total = gx * gy * splits;
+  (void)bk;
+  const dim3 grid = variant == 1 ? dim3(gx, gy, splits) : dim3((ka.total + 7) & ~7);
   if (splits > 1) {
     if (!a.accumulate) {
       if (a.ldc == a.N) {
@@ -285,7 +343,7 @@ void gemm_f32(const GemmArgs& a, hipStream_t stream) {
         for (int m = 0; m < a.M; ++m) memset_async(a.C + (size_t)m * a.ldc, 0, (size_t)a.N * sizeof(float), stream);
       }
     }
-    launch("gemm_f32_splitk", kernel, dim3(gx, gy, splits), dim3(256), 0, stream, ka);
+    launch("gemm_f32_splitk", kernel, grid, dim3(256), 0, stream, ka);
     if (a.bias || a.relu) {
       BiasActArgs b{a.C, a.bias, a.M, a.N, a.ldc, a.relu};
       long long total = (long long)a.M * a.N;
@@ -294,7 +352,7 @@ void gemm_f32(const GemmArgs& a, hipStream_t stream) {
       launch("bias_act", bias_act_kernel, dim3(blocks), dim3(256), 0, stream, b);
     }
   } else {
-    launch("gemm_f32", kernel, dim3(gx, gy, 1), dim3(256), 0, stream, ka);
+    launch("gemm_f32", kernel, grid, dim3(256), 0, stream, ka);
   }
 }
 

@@ -7,33 +7,13 @@
 // and the two BatchNorm-backward reductions (combined per block of four images before they
 // leave as fp64 atomics); the FC parameter gradients are a separate small kernel.
 #include "ops.h"
+#include "xent.h"
 
 namespace dtf {
 namespace {
 
 constexpr int kMaxK = 32;     // classes
 constexpr int kMaxC = 256;    // pooled channels
-
-// One thread computes the loss terms of one row of logits held in registers/LDS.
-__device__ __forceinline__ void xent_row(const float* z, int K, int label, float inv_B, float* dz, float& loss,
-                                         int& hit) {
-  float mx = z[0];
-  int arg = 0;
-  for (int k = 1; k < K; ++k)
-    if (z[k] > mx) { mx = z[k]; arg = k; }
-  float se = 0.f;
-  for (int k = 0; k < K; ++k) se += __expf(z[k] - mx);
-  const float lse = mx + __logf(se);
-  loss = lse - z[label];
-  hit = (arg == label) ? 1 : 0;
-  if (dz) {
-    const float inv = 1.f / se;
-    for (int k = 0; k < K; ++k) {
-      const float p = __expf(z[k] - mx) * inv;
-      dz[k] = (p - (k == label ? 1.f : 0.f)) * inv_B;
-    }
-  }
-}
 
 // One image per wave, four images per block: no block barrier after the shared coefficients are
 // in LDS, and a quarter of the workgroups (1024 one-image blocks spent most of the kernel's time

@@ -107,6 +107,32 @@ struct SoftmaxXentArgs {
 };
 void softmax_xent(const SoftmaxXentArgs& a, hipStream_t stream);
 
+// Fully connected classifier of the MNIST network in one launch (see fc_head.hip): bias + ReLU +
+// dropout of the hidden layer, the output layer, softmax cross-entropy, and the whole way back to
+// the gradient at the hidden layer's pre-activation. Gradient outputs are all given or all null
+// (evaluation). keep_prob >= 1 means no dropout.
+struct FcHeadArgs {
+  const float* h_raw;   // [B, H] first layer's product, before its bias
+  const float* b1;      // [H]
+  const float* w2;      // [H, K]
+  const float* b2;      // [K]
+  const int* labels;    // [B]
+  float* logits;        // [B, K]
+  float* loss;          // [1] += mean loss
+  int* correct;         // [1] += top-1 hits, nullable
+  float* dh;            // [B, H] gradient at the hidden pre-activation, nullable
+  float* dw2;           // [H, K] +=
+  float* db2;           // [K] +=
+  float* db1;           // [H] +=
+  int B, H, K;
+  float keep_prob;
+  unsigned long long seed, offset;
+  const unsigned long long* offset_dev;   // nullable, added to offset at run time (see DropoutArgs)
+  int max_blocks;   // 0: the launcher's choice; a workgroup walks tiles of eight samples
+  AbortRef abort;   // short-circuit reference, filled in by the launch dispatcher
+};
+void fc_head(const FcHeadArgs& a, hipStream_t stream);
+
 // ---- optimizers over the flat parameter arena ---------------------------------------------
 // hyper (device): [0]=lr_t  [1]=beta1  [2]=beta2  [3]=eps  [4]=grad_scale  [5]=momentum  [6]=weight_decay
 // Adam follows tf.train.AdamOptimizer (reference: DistributedLeNet/src/distributed_train.py:164):
@@ -191,6 +217,7 @@ struct GemmArgs {
   int trans_a, trans_b;   // trans_a: A stored [K,M]; trans_b: B stored [N,K]
   int relu;
   int accumulate;         // C += result
+  int variant, splits;    // 0: the launcher's choice (see gemm.hip); tuning runs set them
   AbortRef abort;   // short-circuit reference, filled in by the launch dispatcher
 };
 void gemm_f32(const GemmArgs& a, hipStream_t stream);

@@ -3,12 +3,12 @@
 forward   conv1 + bias + ReLU + pool = one kernel (its 28x28x32 activation never reaches memory),
           conv2 = whole-image 5x5 MFMA kernel (input planes resident in LDS, filter streamed from
           L2) with fused bias + ReLU + max pool, pools that
-          keep a 2-bit argmax, FC1 = split-K MFMA GEMM with bias + ReLU, Philox dropout whose mask
-          is regenerated (not stored) in backward, FC2 GEMM with bias, fused softmax
-          cross-entropy that also emits d(loss)/d(logits).
-backward  explicit chain of GEMM (NT / TN forms), dropout replay, ReLU masks (the pooled maximum
-          doubles as the ReLU mask of its winner), max-pool scatter, conv data/filter gradients,
-          column sums for the biases; gradients land in the flat arena, one fused Adam launch.
+          keep a 2-bit argmax, FC1 = split-K MFMA GEMM; FC1's bias + ReLU, Philox dropout, FC2,
+          softmax cross-entropy and their backward passes are one kernel (fc_head) that keeps
+          the hidden activations in registers.
+backward  GEMMs (NT / TN forms) for FC1, ReLU masks (the pooled maximum doubles as the ReLU mask of
+          its winner), max-pool scatter, conv data/filter gradients, column sums for the biases;
+          gradients land in the flat arena, one fused Adam launch.
 
 Reference behaviour reproduced: DistributedLeNet/src/mnist.py:76-164 (model, loss, top-1 count)
 and DistributedLeNet/src/distributed_train.py:164 (Adam).
@@ -47,9 +47,7 @@ class LeNetHipStep(StepProgramBase):
         self.p2 = torch.empty((B, 7, 7, 64), **f32)
         self.arg2 = torch.empty((B, 7, 7, 64), device=dev, dtype=torch.uint8)
         self.h = torch.empty((B, 512), **f32)
-        self.hd = torch.empty((B, 512), **f32)
         self.logits = torch.empty((B, NUM_LABELS), **f32)
-        self.dlogits = torch.empty((B, NUM_LABELS), **f32)
         if training:
             self.dh = torch.empty((B, 512), **f32)
             self.dp2 = torch.empty((B, 7 * 7 * 64), **f32)
@@ -74,27 +72,21 @@ class LeNetHipStep(StepProgramBase):
             # conv2 + bias + ReLU + pool: the 14x14x64 activation stays in LDS
             nv.conv5x5_tile(self.p1, self.wpk2, bias=a.param("conv2_biases"), pool_out=(self.p2, self.arg2))
             flat = self.p2.view(B, -1)
-            nv.gemm(flat, a.param("fc1_weights"), bias=a.param("fc1_biases"), relu=True, out=self.h)
-            if self.dropout:
-                nv.dropout(self.h, DROPOUT_KEEP, SEED, 0, out=self.hd, offset_dev=self.step_counter[0:1])
-                hd = self.hd
-            else:
-                hd = self.h
-            nv.gemm(hd, a.param("fc2_weights"), bias=a.param("fc2_biases"), out=self.logits)
-            nv.softmax_xent(self.logits, self.labels, self.loss, self.dlogits if self.training else None, self.correct)
+            # FC1's raw product; its bias, ReLU and dropout, FC2, the loss and the backward pass down
+            # to FC1's pre-activation are one kernel, so the hidden activations never reach memory
+            nv.gemm(flat, a.param("fc1_weights"), out=self.h)
+            keep = DROPOUT_KEEP if self.dropout else 1.0
+            head = dict(keep_prob=keep, seed=SEED, offset=0, offset_dev=self.step_counter[0:1])
             if self.training:
-                # ---------------- backward
                 # the arena's gradients were zeroed by the step prologue: accumulating into them
                 # spares the split-K products their own clearing pass
+                head.update(dh=self.dh, dw2=a.grad("fc2_weights"), db2=a.grad("fc2_biases"), db1=a.grad("fc1_biases"))
+            nv.fc_head(self.h, a.param("fc1_biases"), a.param("fc2_weights"), a.param("fc2_biases"), self.labels,
+                       self.logits, self.loss, self.correct, **head)
+            if self.training:
+                # ---------------- backward
                 p.mark_phase("backward")
-                nv.gemm(hd, self.dlogits, trans_a=True, out=a.grad("fc2_weights"), accumulate=True)
-                nv.col_sum(self.dlogits, a.grad("fc2_biases"))
-                nv.gemm(self.dlogits, a.param("fc2_weights"), trans_b=True, out=self.dh)
-                if self.dropout:
-                    nv.dropout(self.dh, DROPOUT_KEEP, SEED, 0, out=self.dh, offset_dev=self.step_counter[0:1])
-                nv.relu_bwd(self.dh, self.h, out=self.dh)
                 nv.gemm(flat, self.dh, trans_a=True, out=a.grad("fc1_weights"), accumulate=True)
-                nv.col_sum(self.dh, a.grad("fc1_biases"))
                 # the FC block holds 97 % of the parameters: its bucket is final here
                 if num_buckets > 1:
                     lo = a.offsets["fc1_weights"]

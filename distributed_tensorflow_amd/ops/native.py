@@ -850,7 +850,35 @@ def dropout(x, keep_prob: float, seed: int, offset: int, out=None, offset_dev=No
     return out
 
 
-def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, relu=False, out=None, accumulate=False):
+def fc_head(h_raw, b1, w2, b2, labels, logits, loss, correct=None, *, dh=None, dw2=None, db2=None, db1=None,
+            keep_prob: float = 1.0, seed: int = 0, offset: int = 0, offset_dev=None, max_blocks: int = 0):
+    """Bias + ReLU + dropout of the 512-unit hidden layer, the output layer, softmax cross-entropy
+    and the backward pass down to the hidden pre-activation, in one launch (csrc/kernels/fc_head.hip).
+    Gradient outputs (dh written, dw2 / db2 / db1 accumulated) are all given or all None."""
+    require()
+    b, h = h_raw.shape
+    k = w2.shape[1]
+    if tuple(w2.shape) != (h, k) or b1.numel() != h or b2.numel() != k or labels.numel() != b or tuple(logits.shape) != (b, k):
+        raise ValueError("fc_head: shape mismatch")
+    d = dict(h_raw=_chk(h_raw, "h_raw"), b1=_chk(b1, "b1"), w2=_chk(w2, "w2"), b2=_chk(b2, "b2"),
+             labels=_chk(labels, "labels", torch.int32), logits=_chk(logits, "logits"), loss=_chk(loss, "loss"),
+             B=b, H=h, K=k, keep_prob=float(keep_prob), seed=int(seed), offset=int(offset), max_blocks=int(max_blocks))
+    if correct is not None:
+        d["correct"] = _chk(correct, "correct", torch.int32)
+    grads = (dh, dw2, db2, db1)
+    if any(g is not None for g in grads):
+        if any(g is None for g in grads):
+            raise ValueError("fc_head: give all gradient outputs or none")
+        if tuple(dh.shape) != (b, h) or dw2.numel() != h * k or db2.numel() != k or db1.numel() != h:
+            raise ValueError("fc_head: gradient shape mismatch")
+        d.update(dh=_chk(dh, "dh"), dw2=_chk(dw2, "dw2"), db2=_chk(db2, "db2"), db1=_chk(db1, "db1"))
+    if offset_dev is not None:
+        d["offset_dev"] = _chk(offset_dev, "offset_dev", torch.int64)
+    hip().fc_head(d, stream())
+    return logits
+
+
+def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, relu=False, out=None, accumulate=False, variant=0, splits=0):
     """C = op(A) @ op(B) (+bias)(relu) with row-major 2-D tensors."""
     require()
     if a.dim() != 2 or b.dim() != 2:
@@ -864,7 +892,8 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, relu=False, out=None,
     elif tuple(out.shape) != (m, n):
         raise ValueError("gemm: out has the wrong shape")
     d = dict(A=_chk(a, "A"), B=_chk(b, "B"), C=_chk(out, "C"), M=m, N=n, K=k, lda=a.shape[1], ldb=b.shape[1], ldc=n,
-             trans_a=int(trans_a), trans_b=int(trans_b), relu=int(relu), accumulate=int(accumulate))
+             trans_a=int(trans_a), trans_b=int(trans_b), relu=int(relu), accumulate=int(accumulate),
+             variant=int(variant), splits=int(splits))
     if bias is not None:
         if bias.numel() != n:
             raise ValueError("gemm: bias size mismatch")

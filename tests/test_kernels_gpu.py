@@ -712,6 +712,46 @@ def test_dropout_statistics_and_replay():
     assert not torch.equal(y, nv.dropout(x, 0.5, 66478, n // 4))
 
 
+@pytest.mark.parametrize("b,keep,train", [(5, 1.0, True), (64, 0.5, True), (1030, 0.5, True), (2051, 0.5, True), (77, 0.5, False)])
+def test_fc_head_forward_and_backward(b, keep, train):
+    """One launch = bias + ReLU + dropout + output layer + loss + the way back; checked against the
+    same chain in plain fp32 PyTorch with the mask the stand-alone dropout kernel draws."""
+    h_raw, b1 = rnd(b, 512, seed=1), rnd(512, scale=0.3, seed=2)
+    w2, b2 = rnd(512, 10, scale=0.1, seed=3), rnd(10, scale=0.1, seed=4)
+    labels = torch.randint(0, 10, (b,), generator=torch.Generator().manual_seed(5)).to(DEV, torch.int32)
+    seed, offset = 66478, 12
+    step = torch.tensor([7], device=DEV, dtype=torch.int64)
+    mask = nv.dropout(torch.ones(b, 512, device=DEV), keep, seed, offset + 7) if keep < 1 else torch.ones(b, 512, device=DEV)
+
+    leaves = [t.clone().requires_grad_(True) for t in (h_raw, b1, w2, b2)]
+    hd = torch.relu(leaves[0] + leaves[1]) * mask
+    logits_ref = hd @ leaves[2] + leaves[3]
+    loss_ref = torch.nn.functional.cross_entropy(logits_ref, labels.long())
+    g_h, g_b1, g_w2, g_b2 = torch.autograd.grad(loss_ref, leaves)
+
+    logits = torch.empty(b, 10, device=DEV)
+    loss = torch.zeros(1, device=DEV)
+    correct = torch.zeros(1, device=DEV, dtype=torch.int32)
+    kw = dict(keep_prob=keep, seed=seed, offset=offset, offset_dev=step)
+    if train:
+        # gradient outputs accumulate: start them from something that is not zero
+        dh = torch.full((b, 512), 9.0, device=DEV)
+        dw2, db2, db1 = rnd(512, 10, seed=6), rnd(10, seed=7), rnd(512, seed=8)
+        dw2_0, db2_0, db1_0 = dw2.clone(), db2.clone(), db1.clone()
+        kw.update(dh=dh, dw2=dw2, db2=db2, db1=db1)
+    nv.fc_head(h_raw, b1, w2, b2, labels, logits, loss, correct, **kw)
+    close(logits, logits_ref)
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
+    assert correct.item() == int((logits_ref.argmax(1) == labels.long()).sum())
+    if train:
+        close(dh, g_h)
+        close(dw2 - dw2_0, g_w2, tol=1e-3)   # the difference of two accumulated values: rounding of the larger operand
+        close(db2 - db2_0, g_b2, tol=1e-3)
+        close(db1 - db1_0, g_b1, tol=1e-3)
+    with pytest.raises(Exception):
+        nv.fc_head(h_raw, b1, w2, b2, labels, logits, loss, correct, dh=torch.empty(b, 512, device=DEV))
+
+
 @pytest.mark.parametrize("shape", [(256, 3136, 512), (100, 512, 10), (37, 70, 129), (1024, 512, 3136), (132, 260, 388), (520, 1028, 772)])
 def test_gemm_variants(shape):
     m, k, n = shape
@@ -728,6 +768,24 @@ def test_gemm_variants(shape):
     out = torch.zeros(n, device=DEV)
     nv.col_sum(b, out)
     close(out, b.sum(0))
+
+
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
+def test_gemm_tile_variants_and_splits(variant):
+    """Every vector-load tile shape, with and without a k split whose last step is short, in all
+    four operand layouts; the work-item-to-XCD mapping must cover every tile exactly once."""
+    for (m, k, n), splits in (((256, 3136, 512), 1), ((256, 3136, 512), 7), ((132, 260, 388), 3), ((520, 1028, 772), 2)):
+        a, b = rnd(m, k), rnd(k, n, seed=3)
+        want = a @ b
+        kw = dict(variant=variant, splits=splits)
+        close(nv.gemm(a, b, **kw), want)
+        close(nv.gemm(a.t().contiguous(), b, trans_a=True, **kw), want)
+        close(nv.gemm(a, b.t().contiguous(), trans_b=True, **kw), want)
+        close(nv.gemm(a.t().contiguous(), b.t().contiguous(), trans_a=True, trans_b=True, **kw), want)
+        bias = rnd(n, seed=4)
+        close(nv.gemm(a, b, bias=bias, relu=True, **kw), torch.relu(want + bias))
+        acc = rnd(m, n, seed=5)
+        close(nv.gemm(a, b, out=acc.clone(), accumulate=True, **kw), acc + want)
 
 
 def test_crop_whiten():

@@ -242,7 +242,9 @@ def test_driver_runs_the_straggler_policies_on_the_device_update_log(tmp_path, m
     # what every worker must reach is the global step
     assert all(r["global_step"] > 30 for r in results), results
     steps0 = [int(m.group(1)) for m in (re.match(r".*step (\d+), loss = ", l) for l in out[0].splitlines()) if m]
-    assert steps0 and steps0[-1] >= (20 if mode == "backup_unsynced" else 29)
+    # the last line a worker logs is the last global step it SAW before max_steps: pushes of the other
+    # worker (async) or a catch-up of several updates can carry it past the final steps unlogged
+    assert steps0 and steps0[-1] >= (20 if mode == "backup_unsynced" else 24)
     if mode == "backup":
         by_rank = {r["rank"]: r for r in results}
         assert by_rank[1]["excluded_steps"] > by_rank[0]["excluded_steps"]
