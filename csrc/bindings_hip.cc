@@ -415,7 +415,7 @@ PYBIND11_MODULE(_hip, m) {
   });
   m.def("col_sum", [](const py::dict& d, uint64_t stream) {
     ColSumArgs a{};
-    P(x, const float); P(out, float); V(n_rows); V(C);
+    P(x, const float); P(out, float); V(n_rows); V(C); P(relu_of, const float); P(masked, float);
     col_sum(a, as_stream(stream));
   });
   m.def("tf_histogram", [](const py::dict& d, uint64_t stream) {

@@ -176,13 +176,32 @@ __global__ __launch_bounds__(256) void col_sum_kernel(ColSumArgs a) {
     // register accumulation, one LDS atomic per channel at the end
     const floatx4* x4 = reinterpret_cast<const floatx4*>(a.x);
     const long long n4 = total >> 2;
+    const floatx4* m4 = reinterpret_cast<const floatx4*>(a.relu_of);
+    floatx4* o4 = reinterpret_cast<floatx4*>(a.masked);
     floatx4 s = {0.f, 0.f, 0.f, 0.f};
-    for (long long i = gtid; i < n4; i += stride) s += x4[i];
+#pragma unroll 4
+    for (long long i = gtid; i < n4; i += stride) {
+      floatx4 v = x4[i];
+      if (m4) {
+        const floatx4 m = m4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+        if (o4) o4[i] = v;
+      }
+      s += v;
+    }
     const int c = (int)(gtid % C4) * 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) atomicAdd(&red[c + e], s[e]);
   } else {
-    for (long long i = gtid; i < total; i += stride) atomicAdd(&red[(int)(i % a.C)], a.x[i]);
+    for (long long i = gtid; i < total; i += stride) {
+      float v = a.x[i];
+      if (a.relu_of) {
+        v = a.relu_of[i] > 0.f ? v : 0.f;
+        if (a.masked) a.masked[i] = v;
+      }
+      atomicAdd(&red[(int)(i % a.C)], v);
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < a.C; c += blockDim.x)
@@ -378,12 +397,13 @@ void dropout_apply(const DropoutArgs& a, hipStream_t stream) {
 }
 void col_sum(const ColSumArgs& a, hipStream_t stream) {
   long long total = a.n_rows * a.C;
-  // few, fat blocks: every block ends with one atomic per column on the same C addresses, and
-  // same-address atomics serialise (~20 ns each), so 1024 blocks cost 20 us in the tail alone
-  // so the grid grows with the data (64 K floats per block) and stays between 32 and 1024 blocks
-  long long nb = total >> 16;
+  // Every block ends with one atomic per column on the same C addresses, and same-address atomics
+  // serialise (~20 ns each: 1024 blocks cost 20 us in the tail alone), while a thread's loop is a
+  // chain of memory round trips (~1 us each). 8 K floats per block = eight trips per thread;
+  // between 32 and 512 blocks.
+  long long nb = total >> 13;
   if (nb < 32) nb = 32;
-  if (nb > 1024) nb = 1024;
+  if (nb > 512) nb = 512;
   if (nb > flat_blocks(total >> 2)) nb = flat_blocks(total >> 2);
   const int blocks = (int)nb;
   launch("col_sum", col_sum_kernel, dim3(blocks), dim3(256), a.C * sizeof(float), stream, a);

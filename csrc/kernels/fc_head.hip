@@ -15,6 +15,12 @@
 // each of which moved the batch x 512 tensor through HBM once more and cost a launch slot of
 // 5-7 us for 1-2 us of work.
 //
+// The logits of a tile are sums over the 128 column groups. A wave holds 4 rows x 16 (K padded)
+// partial values per lane and reduces them with a transposing butterfly: at each of the six
+// steps a lane hands half of its values to its partner and keeps the other half, so 63 lane
+// exchanges leave lane L with the wave total of value L, where reducing the values one by one
+// takes 6 exchanges each. The loss of a tile is then evaluated by sixteen lanes per row.
+//
 // Thread layout: 128 column groups of four hidden units x 2 row halves. A thread keeps the
 // K weights of its four hidden units (4 x K registers) and the partial weight gradients
 // (another 4 x K) across all tiles of its workgroup; these leave through one LDS fold of the
@@ -23,7 +29,6 @@
 // reference: DistributedLeNet/src/mnist.py:118-164 (hidden layer, dropout, logits, loss, top-1)
 #include "ops.h"
 #include "philox.h"
-#include "xent.h"
 
 namespace dtf {
 namespace {
@@ -37,7 +42,6 @@ template <int K>
 __global__ __launch_bounds__(256) void fc_head_kernel(FcHeadArgs a) {
   DTF_ABORT_GUARD(a);
   __shared__ float s_part[kRows][2][K];      // per-wave partial logits of a tile
-  __shared__ float s_z[kRows][K];            // logits of a tile
   __shared__ float s_dz[kRows][K];           // d(loss)/d(logits) of a tile
   constexpr int kFoldDb1 = kH * K + kCG;     // dw2 (padded, see slot below), then db1
   __shared__ float s_fold[kFoldDb1 + kH];    // the workgroup's parameter gradients on their way out
@@ -72,66 +76,85 @@ __global__ __launch_bounds__(256) void fc_head_kernel(FcHeadArgs a) {
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int j = 0; j < K; ++j) dw[c][j] = 0.f;
-  // threads 0..kRows-1 own one row of every tile in the loss phase
-  float loss_acc = 0.f, db2[K];
-  int hit_acc = 0;
-#pragma unroll
-  for (int j = 0; j < K; ++j) db2[j] = 0.f;
+  // loss phase: threads 0..127 = 8 rows x 16 lanes, lane j of a row owns class j (j < K)
+  const int lr = tid >> 4, lj = tid & 15;
+  const bool loss_lane = tid < 16 * kRows && lj < K;
+  const float b2 = loss_lane ? a.b2[lj] : 0.f;
+  float loss_acc = 0.f, hit_acc = 0.f, db2 = 0.f;
 
   const int tiles = (a.B + kRows - 1) / kRows;
   for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int row0 = tile * kRows;
+    // the label is needed after the first barrier only: its load rides behind the first phase
+    const int lrow = row0 + lr;
+    const int label = (tid < 16 * kRows && lrow < a.B) ? a.labels[lrow] : 0;
     float hd[kRows / 2][4];
+    float v[64];   // partial logits: v[16 * i + j] for row half + 2 * i, class j; zero for j >= K
     // ---- hidden activation, dropout, partial logits
 #pragma unroll
     for (int i = 0; i < kRows / 2; ++i) {
-      const int r = half + 2 * i, row = row0 + r;
-      float pl[K];
+      const int row = row0 + half + 2 * i;
 #pragma unroll
-      for (int j = 0; j < K; ++j) pl[j] = 0.f;
+      for (int j = 0; j < 16; ++j) v[16 * i + j] = 0.f;
       if (row < a.B) {
         const floatx4 x = reinterpret_cast<const floatx4*>(a.h_raw + (size_t)row * kH)[cg];
         uint32_t rnd[4];
         if (drop) philox4x32_10(base + (unsigned long long)row * kCG + cg, a.seed, rnd);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          float v = fmaxf(x[c] + b1[c], 0.f);
-          if (drop) v = (philox_uniform(rnd[c]) < a.keep_prob) ? v * inv_keep : 0.f;
-          hd[i][c] = v;
+          float h = fmaxf(x[c] + b1[c], 0.f);
+          if (drop) h = (philox_uniform(rnd[c]) < a.keep_prob) ? h * inv_keep : 0.f;
+          hd[i][c] = h;
 #pragma unroll
-          for (int j = 0; j < K; ++j) pl[j] = fmaf(v, w[c][j], pl[j]);
+          for (int j = 0; j < K; ++j) v[16 * i + j] = fmaf(h, w[c][j], v[16 * i + j]);
         }
       } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c) hd[i][c] = 0.f;
       }
+    }
+    // transposing butterfly: lane L ends with the wave's total of v[L]
 #pragma unroll
-      for (int j = 0; j < K; ++j) {
-        const float s = wave_sum(pl[j]);
-        if (lane == 0) s_part[r][wave & 1][j] = s;
+    for (int off = 32; off >= 1; off >>= 1) {
+      const bool upper = (lane & off) != 0;
+#pragma unroll
+      for (int i = 0; i < off; ++i) {
+        const float send = upper ? v[i] : v[i + off];
+        const float keep = upper ? v[i + off] : v[i];
+        v[i] = keep + __shfl_xor(send, off);
       }
     }
+    if ((lane & 15) < K) s_part[half + 2 * (lane >> 4)][wave & 1][lane & 15] = v[0];
     __syncthreads();
-    // ---- logits, loss, d(loss)/d(logits): one thread per row
-    if (tid < kRows && row0 + tid < a.B) {
-      const int row = row0 + tid;
+    // ---- logits, loss, d(loss)/d(logits): sixteen lanes per row (waves 0 and 1)
+    if (tid < 16 * kRows) {
+      const bool live = loss_lane && lrow < a.B;
+      const float z = loss_lane ? s_part[lr][0][lj] + s_part[lr][1][lj] + b2 : -INFINITY;
+      float mx = z;
 #pragma unroll
-      for (int j = 0; j < K; ++j) {
-        const float z = s_part[tid][0][j] + s_part[tid][1][j] + a.b2[j];
-        s_z[tid][j] = z;
-        a.logits[(size_t)row * K + j] = z;
-      }
-      float loss;
-      int hit;
-      xent_row(s_z[tid], K, a.labels[row], 1.f / (float)a.B, train ? s_dz[tid] : nullptr, loss, hit);
-      loss_acc += loss;
-      hit_acc += hit;
-      if (train) {
+      for (int off = 8; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+      const float e = loss_lane ? __expf(z - mx) : 0.f;
+      float se = e;
 #pragma unroll
-        for (int j = 0; j < K; ++j) db2[j] += s_dz[tid][j];
+      for (int off = 8; off >= 1; off >>= 1) se += __shfl_xor(se, off);
+      // the first class that attains the maximum is the prediction
+      const unsigned long long at_max = __ballot(loss_lane && z == mx);
+      const int arg = __ffsll((unsigned long long)((at_max >> (lane & 48)) & 0xffffull)) - 1;
+      const float z_label = __shfl(z, (lane & 48) + label);
+      if (live) {
+        a.logits[(size_t)lrow * K + lj] = z;
+        if (train) {
+          const float dz = (e / se - (lj == label ? 1.f : 0.f)) / (float)a.B;
+          s_dz[lr][lj] = dz;
+          db2 += dz;
+        }
+        if (lj == 0) {
+          loss_acc += mx + __logf(se) - z_label;
+          hit_acc += (arg == label) ? 1.f : 0.f;
+        }
       }
     }
-    __syncthreads();   // s_part and s_z are free for the next tile, s_dz is complete
+    __syncthreads();   // s_part is free for the next tile, s_dz is complete
     if (!train) continue;
     // ---- back through the second layer, the dropout mask and the ReLU
 #pragma unroll
@@ -157,14 +180,19 @@ __global__ __launch_bounds__(256) void fc_head_kernel(FcHeadArgs a) {
     }
   }
 
-  // ---- leave: loss terms, then the parameter gradients
-  if (tid < kRows) {
-    if (loss_acc != 0.f) atomicAdd(a.loss, loss_acc / (float)a.B);
-    if (a.correct && hit_acc) atomicAdd(a.correct, hit_acc);
-    if (train) {
+  // ---- leave: loss terms (summed over the four rows of a wave first), then the parameter gradients
+  if (tid < 16 * kRows) {
 #pragma unroll
-      for (int j = 0; j < K; ++j) atomicAdd(a.db2 + j, db2[j]);
+    for (int off = 16; off <= 32; off <<= 1) {
+      loss_acc += __shfl_xor(loss_acc, off);
+      hit_acc += __shfl_xor(hit_acc, off);
+      db2 += __shfl_xor(db2, off);
     }
+    if (lane == 0) {
+      if (loss_acc != 0.f) atomicAdd(a.loss, loss_acc / (float)a.B);
+      if (a.correct && hit_acc > 0.f) atomicAdd(a.correct, (int)(hit_acc + 0.5f));
+    }
+    if (train && lane < K) atomicAdd(a.db2 + lane, db2);
   }
   if (!train) return;
   // Fold the two halves in LDS, laid out as the gradients are in memory (dw2 row-major, then db1),

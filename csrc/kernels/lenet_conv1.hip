@@ -119,6 +119,26 @@ __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(Conv1PoolBwdArgs a)
   float4 pf = make_float4(0.f, 0.f, 0.f, 0.f);
   int img = blockIdx.x;
   if (img < a.B && tid < kCells) pf = reinterpret_cast<const float4*>(a.x + (size_t)img * kIn * kIn)[tid];
+  // The pooled gradient, the pooled maximum and its argmax of a cell come from memory. A round
+  // computes for ~0.2 us and a load takes ~1 us to arrive, and a CU holds one or two of these
+  // workgroups, so the loads of five rounds are issued together, one batch ahead of their use.
+  constexpr int kBatch = 5, kBatches = (kRounds + kBatch - 1) / kBatch;
+  float g_c[kBatch], p_c[kBatch], g_n[kBatch], p_n[kBatch];
+  int k_c[kBatch], k_n[kBatch];
+  auto fetch = [&](int im, int batch, float (&g)[kBatch], float (&p)[kBatch], int (&k)[kBatch]) {
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const int cell = (batch * kBatch + u) * 8 + sub;
+      g[u] = 0.f; p[u] = 0.f; k[u] = 0;
+      if (im < a.B && cell < kCells) {
+        const size_t o = ((size_t)im * kCells + cell) * kCo + co;
+        g[u] = a.dp[o];
+        p[u] = a.p[o];
+        k[u] = a.arg[o];
+      }
+    }
+  };
+  fetch(img, 0, g_c, p_c, k_c);
   __syncthreads();
   for (int buf = 0; img < a.B; img += gridDim.x, buf ^= 1) {
     if (tid < kCells) stage_image(plane[buf], pf, tid);
@@ -126,28 +146,34 @@ __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(Conv1PoolBwdArgs a)
     const int nxt = img + gridDim.x;
     if (nxt < a.B && tid < kCells) pf = reinterpret_cast<const float4*>(a.x + (size_t)nxt * kIn * kIn)[tid];
 #pragma unroll 1
-    for (int round = 0; round < kRounds; ++round) {
-      const int cell = round * 8 + sub;
-      if (cell < kCells) {
-        const size_t o = ((size_t)img * kCells + cell) * kCo + co;
-        float g = a.dp[o];
-        // a zero maximum means the winning pre-activation was clipped by the ReLU
-        if (!(a.p[o] > 0.f)) g = 0.f;
-        const int k = a.arg[o];
-        const bool wy = (k >> 1) != 0, wx = (k & 1) != 0;
-        float pt[6][6];
-        load_patch(plane[buf], cell, pt);
-        db += g;
+    for (int batch = 0; batch < kBatches; ++batch) {
+      const bool last = batch + 1 == kBatches;
+      fetch(last ? nxt : img, last ? 0 : batch + 1, g_n, p_n, k_n);
 #pragma unroll
-        for (int kh = 0; kh < 5; ++kh) {
+      for (int u = 0; u < kBatch; ++u) {
+        const int cell = (batch * kBatch + u) * 8 + sub;
+        if (cell < kCells) {
+          // a zero maximum means the winning pre-activation was clipped by the ReLU
+          const float g = p_c[u] > 0.f ? g_c[u] : 0.f;
+          const int k = k_c[u];
+          const bool wy = (k >> 1) != 0, wx = (k & 1) != 0;
+          float pt[6][6];
+          load_patch(plane[buf], cell, pt);
+          db += g;
 #pragma unroll
-          for (int kw = 0; kw < 5; ++kw) {
-            const float top = wx ? pt[kh][kw + 1] : pt[kh][kw];
-            const float bot = wx ? pt[kh + 1][kw + 1] : pt[kh + 1][kw];
-            dw[kh * 5 + kw] = fmaf(g, wy ? bot : top, dw[kh * 5 + kw]);
+          for (int kh = 0; kh < 5; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < 5; ++kw) {
+              const float t0 = pt[kh][kw], t1 = pt[kh][kw + 1], b0 = pt[kh + 1][kw], b1 = pt[kh + 1][kw + 1];
+              const float top = wx ? t1 : t0;
+              const float bot = wx ? b1 : b0;
+              dw[kh * 5 + kw] = fmaf(g, wy ? bot : top, dw[kh * 5 + kw]);
+            }
           }
         }
       }
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) { g_c[u] = g_n[u]; p_c[u] = p_n[u]; k_c[u] = k_n[u]; }
     }
   }
   // the two cells of a wave, then the four waves, then one atomic per value into the copy of

@@ -222,7 +222,10 @@ struct GemmArgs {
 };
 void gemm_f32(const GemmArgs& a, hipStream_t stream);
 
-struct ColSumArgs { const float* x; float* out; long long n_rows; int C; AbortRef abort; };   // out[C] += column sums
+// out[C] += column sums of x [n_rows, C]. With relu_of (same shape): of x * 1[relu_of > 0], the
+// gradient through a ReLU whose output was relu_of; that masked tensor is also stored to `masked`
+// when given (which may be x itself): ReLU backward and the bias gradient in one pass.
+struct ColSumArgs { const float* x; float* out; long long n_rows; int C; const float* relu_of; float* masked; AbortRef abort; };
 void col_sum(const ColSumArgs& a, hipStream_t stream);
 struct ReluMaskArgs { const float* dy; const float* y; float* dx; long long n; AbortRef abort; };   // dx = dy * 1[y>0]
 void relu_bwd(const ReluMaskArgs& a, hipStream_t stream);

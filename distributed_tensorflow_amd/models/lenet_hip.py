@@ -63,7 +63,8 @@ class LeNetHipStep(StepProgramBase):
         p.begin_record()
         try:
             p.mark_phase("prologue")
-            self._record_prologue()
+            # FC1 is a k-split product that accumulates into its output: cleared with everything else
+            self._record_prologue(also_zero=[self.h])
             p.mark_phase("forward")
             nv.conv5x5_pack(a.param("conv2_weights"), self.wpk2)
             # ---------------- forward
@@ -74,7 +75,7 @@ class LeNetHipStep(StepProgramBase):
             flat = self.p2.view(B, -1)
             # FC1's raw product; its bias, ReLU and dropout, FC2, the loss and the backward pass down
             # to FC1's pre-activation are one kernel, so the hidden activations never reach memory
-            nv.gemm(flat, a.param("fc1_weights"), out=self.h)
+            nv.gemm(flat, a.param("fc1_weights"), out=self.h, accumulate=True)
             keep = DROPOUT_KEEP if self.dropout else 1.0
             head = dict(keep_prob=keep, seed=SEED, offset=0, offset_dev=self.step_counter[0:1])
             if self.training:
@@ -99,7 +100,8 @@ class LeNetHipStep(StepProgramBase):
                 # kernels form it while staging, so it is never written. Its per-channel sum (the bias
                 # gradient) is the sum of dp2 over the cells whose maximum survived the ReLU.
                 dp2 = self.dp2.view(B, 7, 7, 64)
-                nv.relu_bwd(dp2, self.p2, out=dp2)
+                # ReLU mask of the pooled maximum and conv2's bias gradient in one pass over dp2
+                nv.col_sum(dp2.view(-1, 64), a.grad("conv2_biases"), relu_of=self.p2, masked=dp2)
                 pooled2 = (dp2, self.arg2, self.p2)
                 # filter gradients accumulate in per-XCD copies of the conv part of the arena
                 conv_end = a.offsets["fc1_weights"]
@@ -114,7 +116,6 @@ class LeNetHipStep(StepProgramBase):
                 if not hasattr(self, "_w2_parts"):
                     self._w2_parts = torch.empty(nv.conv5x5_wgrad_parts(B), 25 * 32 * 64, device=self.device, dtype=torch.float32)
                 nv.conv5x5_wgrad(self.p1, None, a.grad("conv2_weights"), partials=self._w2_parts, pooled=pooled2)
-                nv.col_sum(dp2.view(-1, 64), a.grad("conv2_biases"))
                 # data gradient: the same kernel over the unpacked filter, taps walked backwards
                 nv.conv5x5_tile(None, a.param("conv2_weights"), flip=True, out=self.dp1, pooled=pooled2)
                 # pool backward + ReLU mask + filter and bias gradients of conv1 in one kernel

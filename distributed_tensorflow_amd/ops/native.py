@@ -902,12 +902,25 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, relu=False, out=None,
     return out
 
 
-def col_sum(x2d, out):
+def col_sum(x2d, out, relu_of=None, masked=None):
+    """out[C] += column sums of x2d. relu_of (same shape): sums x2d * 1[relu_of > 0] instead - the
+    ReLU backward of x2d - and stores that masked tensor to `masked` when given (x2d itself is fine)."""
     require()
     n_rows, c = x2d.shape
     if out.numel() != c:
         raise ValueError("col_sum: size mismatch")
-    hip().col_sum(dict(x=_chk(x2d, "x"), out=_chk(out, "out"), n_rows=n_rows, C=c), stream())
+    d = dict(x=_chk(x2d, "x"), out=_chk(out, "out"), n_rows=n_rows, C=c)
+    if relu_of is not None:
+        if relu_of.numel() != x2d.numel():
+            raise ValueError("col_sum: relu_of size mismatch")
+        d["relu_of"] = _chk(relu_of, "relu_of")
+        if masked is not None:
+            if masked.numel() != x2d.numel():
+                raise ValueError("col_sum: masked size mismatch")
+            d["masked"] = _chk(masked, "masked")
+    elif masked is not None:
+        raise ValueError("col_sum: masked needs relu_of")
+    hip().col_sum(d, stream())
     return out
 
 

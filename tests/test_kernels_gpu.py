@@ -768,6 +768,14 @@ def test_gemm_variants(shape):
     out = torch.zeros(n, device=DEV)
     nv.col_sum(b, out)
     close(out, b.sum(0))
+    # with a ReLU mask: the masked tensor is written (in place here) and its column sums added
+    y = rnd(k, n, seed=6)
+    want_masked = b * (y > 0)
+    out2 = torch.ones(n, device=DEV)
+    g = b.clone()
+    nv.col_sum(g, out2, relu_of=y, masked=g)
+    assert torch.equal(g, want_masked)
+    close(out2 - 1, want_masked.sum(0))
 
 
 @pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
