@@ -55,7 +55,7 @@ __device__ __forceinline__ float4 pooled_value(const PooledChunk& c, unsigned po
 
 template <int CIN, int COUT, int IMGS>
 struct C5 {
-  static constexpr int PS = CIN + 4;                 // LDS pixel stride (floats)
+  static constexpr int PS = CIN + 8;                 // LDS pixel stride (floats): +8 halves the bank conflicts of the pixel-operand reads against +4 (14-pixel rows never line up with the 16-lane read groups)
   static constexpr int PX = IMGS * kImgPx;           // pixels per tile
   static constexpr int NT = (PX + 15) / 16;          // 16-pixel MFMA tiles per workgroup tile
   static constexpr int MT = COUT / 16;               // 16-channel output tiles
