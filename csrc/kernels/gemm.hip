@@ -131,26 +131,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmKArgs ka) {
 // with one ds_read_b128 per fragment, row-contiguous ones ([k][row], the transposed forms) with
 // four conflict-free ds_read_b32 - no transposing scatter into LDS either way.
 //
-// Two shapes are in use:
+// Shapes in use (the others are kept for bench/gemm_sweep.py):
+//   64x64, 64 deep     batch-sized products, split along k. A workgroup of such a product walks a
+//                      few hundred k: with the general kernel's 32-deep step and scalar loads that
+//                      is a dozen round trips to memory with little in flight each.
 //   128x128, 32 deep   large products: 8 operand fragments feed 64 MFMAs per 16 k.
-//   64x64, 128 deep    batch-sized products split along k. A workgroup of such a product walks a
-//                      few hundred k: with a 32-deep step that is a dozen round trips to memory
-//                      with one step of loads in flight each, and the kernel's time is those
-//                      round trips, not its arithmetic. A 128-deep step keeps four times the
-//                      bytes in flight per round trip.
 constexpr int TM = 128, TN = 128, TK = 32;
 
-template <int ROWS, int DEPTH, bool KC>   // KC: the operand is k-contiguous in memory (ld = row stride), else row-contiguous (ld = k stride)
+template <int ROWS, int DEPTH, bool KC, int THREADS = 256>   // KC: the operand is k-contiguous in memory (ld = row stride), else row-contiguous (ld = k stride)
 struct OperandTile {
   static constexpr int LDK = DEPTH + 4;   // [row][k] layout: row stride
   static constexpr int LDR = ROWS + 4;    // [k][row] layout: k stride
   static constexpr int FLOATS = KC ? ROWS * LDK : DEPTH * LDR;
-  static constexpr int NV = ROWS * DEPTH / 4 / 256;   // float4 per thread and k-step
-  static_assert(ROWS * DEPTH % 1024 == 0, "a k-step of an operand is a whole number of float4 per thread");
+  static constexpr int NV = ROWS * DEPTH / 4 / THREADS;   // float4 per thread and k-step
+  static_assert(ROWS * DEPTH % (4 * THREADS) == 0, "a k-step of an operand is a whole number of float4 per thread");
   __device__ static void fetch(const float* __restrict__ src, int ld, int row0, int rows, int k0, int k_end, int tid, float4 (&r)[NV]) {
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
-      const int e = tid + it * 256;
+      const int e = tid + it * THREADS;
       int row, k;
       if (KC) { k = (e % (DEPTH / 4)) * 4; row = e / (DEPTH / 4); } else { row = (e % (ROWS / 4)) * 4; k = e / (ROWS / 4); }
       const int gr = row0 + row, gk = k0 + k;
@@ -162,7 +160,7 @@ struct OperandTile {
   __device__ static void commit(float* lds, int tid, const float4 (&r)[NV]) {
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
-      const int e = tid + it * 256;
+      const int e = tid + it * THREADS;
       if (KC) *reinterpret_cast<float4*>(lds + (e / (DEPTH / 4)) * LDK + (e % (DEPTH / 4)) * 4) = r[it];
       else *reinterpret_cast<float4*>(lds + (e / (ROWS / 4)) * LDR + (e % (ROWS / 4)) * 4) = r[it];
     }
@@ -177,16 +175,25 @@ struct OperandTile {
   }
 };
 
-template <int TM_, int TN_, int TK_, bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_tile_kernel(GemmKArgs ka) {
+// WK = 2: eight waves. Waves 4-7 cover the same four quadrants as waves 0-3 and take every other
+// 16-deep k group of a step; the two partial tiles are added through LDS at the end. Same bytes
+// from L2 per workgroup, twice the waves to issue MFMAs and to keep loads in flight - for grids
+// that put one workgroup on a CU.
+template <int TM_, int TN_, int TK_, bool TA, bool TB, int WK = 1>
+__global__ __launch_bounds__(256 * WK) void gemm_tile_kernel(GemmKArgs ka) {
   DTF_ABORT_GUARD(ka);
   const GemmArgs& a = ka.g;
-  using TileA = OperandTile<TM_, TK_, !TA>;   // A [M,K] row-major is k-contiguous; trans_a stores [K,M]
-  using TileB = OperandTile<TN_, TK_, TB>;    // B [K,N] row-major is n-contiguous; trans_b stores [N,K]
+  using TileA = OperandTile<TM_, TK_, !TA, 256 * WK>;   // A [M,K] row-major is k-contiguous; trans_a stores [K,M]
+  using TileB = OperandTile<TN_, TK_, TB, 256 * WK>;    // B [K,N] row-major is n-contiguous; trans_b stores [N,K]
   constexpr int MI = TM_ / 32, NJ = TN_ / 32;  // MFMA tiles per wave
-  __shared__ __attribute__((aligned(16))) float As[TileA::FLOATS];
-  __shared__ __attribute__((aligned(16))) float Bs[TileB::FLOATS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int kOperandFloats = TileA::FLOATS + TileB::FLOATS;
+  constexpr int kFoldFloats = WK > 1 ? MI * NJ * 4 * 256 : 0;
+  __shared__ __attribute__((aligned(16))) float smem[kOperandFloats > kFoldFloats ? kOperandFloats : kFoldFloats];
+  float* As = smem;
+  float* Bs = smem + TileA::FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave8 & 3, kh = wave8 >> 2;
   const int q = lane >> 4, l15 = lane & 15;
   // Workgroups go to the eight XCDs round-robin by their linear id, and every XCD has its own L2.
   // Work item t = (id % 8) * (items per XCD) + id / 8 gives each XCD one contiguous range of
@@ -226,6 +233,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmKArgs ka) {
 #pragma unroll
     for (int kg = 0; kg < TK_ / 16; ++kg) {
       if (kg * 16 >= k_left) break;   // the last step of a split may be short: its empty groups hold zeros
+      if (WK > 1 && (kg % WK) != kh) continue;
       floatx4 av[MI], bv[NJ];
 #pragma unroll
       for (int i = 0; i < MI; ++i) av[i] = TileA::frag(As, wm + i * 16 + l15, kg, q);
@@ -239,6 +247,23 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmKArgs ka) {
           for (int j = 0; j < NJ; ++j) acc[i][j] = DTF_MFMA16(av[i][s], bv[j][s], acc[i][j]);
     }
     __syncthreads();
+  }
+
+  if (WK > 1) {
+    // the operand tiles are dead (barrier above): the upper waves park their partial tile there
+    floatx4* fold = reinterpret_cast<floatx4*>(smem);
+    if (kh == 1) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fold[((wave * MI + i) * NJ + j) * 64 + lane] = acc[i][j];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] += fold[((wave * MI + i) * NJ + j) * 64 + lane];
   }
 
 #pragma unroll
@@ -264,10 +289,10 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmKArgs ka) {
 }
 
 using GemmKernel = void (*)(GemmKArgs);
-template <int TM_, int TN_, int TK_>
+template <int TM_, int TN_, int TK_, int WK = 1>
 GemmKernel tile_kernel(bool ta, bool tb) {
-  return ta ? (tb ? gemm_tile_kernel<TM_, TN_, TK_, true, true> : gemm_tile_kernel<TM_, TN_, TK_, true, false>)
-            : (tb ? gemm_tile_kernel<TM_, TN_, TK_, false, true> : gemm_tile_kernel<TM_, TN_, TK_, false, false>);
+  return ta ? (tb ? gemm_tile_kernel<TM_, TN_, TK_, true, true, WK> : gemm_tile_kernel<TM_, TN_, TK_, true, false, WK>)
+            : (tb ? gemm_tile_kernel<TM_, TN_, TK_, false, true, WK> : gemm_tile_kernel<TM_, TN_, TK_, false, false, WK>);
 }
 
 struct BiasActArgs { float* C; const float* bias; int M, N, ldc, relu; AbortRef abort; };
@@ -290,15 +315,21 @@ __global__ __launch_bounds__(256) void bias_act_kernel(BiasActArgs a) {
 void gemm_f32(const GemmArgs& a, hipStream_t stream) {
   const bool aligned = ((a.M | a.N | a.K | a.lda | a.ldb) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(a.B) & 15) == 0;
-  // variant (0 = choose here): 1 general 64x64x32, 2 128x128x32, 3 64x64x128, 4 64x128x64, 5 128x128x64, 6 64x64x64
+  // variant (0 = choose here): 1 general 64x64x32, 2 128x128x32, 3 64x64x128, 4 64x128x64, 5 128x128x64, 6 64x64x64,
+  // 7 64x64x64 with eight waves, 8 64x64x128 with eight waves
   // Measured on the fully connected products of the MNIST network (bench/gemm_sweep.py, batch 128
   // to 2048): the 64x64 tile with a 64-deep step is the fastest or within 5 % of it on every one
   // of them (20-30 % ahead of the 32-deep general kernel and, up to batch 2048, of the 128x128
   // tile, which leaves most CUs without work at these sizes).
   int variant = a.variant;
-  if (variant == 0) variant = ceil_div(a.M, TM) * ceil_div(a.N, TN) >= 512 ? 2 : 6;
+  if (variant == 0) {
+    // eight waves (7) where the tiles are few enough to leave a workgroup alone on its CU (the
+    // batch <= 256 products: 3-8 % faster); with more tiles no different or slightly slower
+    const int tiles64 = ceil_div(a.M, 64) * ceil_div(a.N, 64);
+    variant = ceil_div(a.M, TM) * ceil_div(a.N, TN) >= 512 ? 2 : tiles64 <= 200 ? 7 : 6;
+  }
   if (!aligned) variant = 1;
-  int bm, bn, bk;
+  int bm, bn, bk, threads = 256;
   GemmKernel kernel;
   switch (variant) {
     case 2: bm = 128; bn = 128; bk = 32; kernel = tile_kernel<128, 128, 32>(a.trans_a, a.trans_b); break;
@@ -306,6 +337,8 @@ void gemm_f32(const GemmArgs& a, hipStream_t stream) {
     case 4: bm = 64; bn = 128; bk = 64; kernel = tile_kernel<64, 128, 64>(a.trans_a, a.trans_b); break;
     case 5: bm = 128; bn = 128; bk = 64; kernel = tile_kernel<128, 128, 64>(a.trans_a, a.trans_b); break;
     case 6: bm = 64; bn = 64; bk = 64; kernel = tile_kernel<64, 64, 64>(a.trans_a, a.trans_b); break;
+    case 7: bm = 64; bn = 64; bk = 64; kernel = tile_kernel<64, 64, 64, 2>(a.trans_a, a.trans_b); threads = 512; break;
+    case 8: bm = 64; bn = 64; bk = 128; kernel = tile_kernel<64, 64, 128, 2>(a.trans_a, a.trans_b); threads = 512; break;
     default: variant = 1; bm = BM; bn = BN; bk = BK; kernel = gemm_kernel; break;
   }
   const int gx = ceil_div(a.N, bn), gy = ceil_div(a.M, bm);
@@ -343,7 +376,7 @@ void gemm_f32(const GemmArgs& a, hipStream_t stream) {
         for (int m = 0; m < a.M; ++m) memset_async(a.C + (size_t)m * a.ldc, 0, (size_t)a.N * sizeof(float), stream);
       }
     }
-    launch("gemm_f32_splitk", kernel, grid, dim3(256), 0, stream, ka);
+    launch("gemm_f32_splitk", kernel, grid, dim3(threads), 0, stream, ka);
     if (a.bias || a.relu) {
       BiasActArgs b{a.C, a.bias, a.M, a.N, a.ldc, a.relu};
       long long total = (long long)a.M * a.N;
@@ -352,7 +385,7 @@ void gemm_f32(const GemmArgs& a, hipStream_t stream) {
       launch("bias_act", bias_act_kernel, dim3(blocks), dim3(256), 0, stream, b);
     }
   } else {
-    launch("gemm_f32", kernel, grid, dim3(256), 0, stream, ka);
+    launch("gemm_f32", kernel, grid, dim3(threads), 0, stream, ka);
   }
 }
 
