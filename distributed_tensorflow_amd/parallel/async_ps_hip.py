@@ -71,15 +71,27 @@ class DeviceAsyncShards(AsyncParameterShards):
         self.stream.synchronize()
         handles = comm.all_gather_object(tuple(h.ipc_export(p) for p in self._own))
         self._ctl, self._shard, self._inbox, self._imported = [], [], [], []
-        for r, hs in enumerate(handles):
-            if r == self.rank:
-                ptrs = tuple(self._own)
-            else:
-                ptrs = tuple(int(h.ipc_import(x)) for x in hs)
-                self._imported += list(ptrs)
-            self._ctl.append(ptrs[0])
-            self._shard.append(ptrs[1])
-            self._inbox.append(ptrs[2])
+        # a rank that cannot map a peer's HBM (different nodes, no peer access) must not leave the
+        # others waiting in the next collective: the ranks exchange the outcome and fail together
+        error = None
+        try:
+            for r, hs in enumerate(handles):
+                if r == self.rank:
+                    ptrs = list(self._own)
+                else:
+                    ptrs = []
+                    for x in hs:
+                        ptrs.append(int(h.ipc_import(x)))
+                        self._imported.append(ptrs[-1])
+                self._ctl.append(ptrs[0])
+                self._shard.append(ptrs[1])
+                self._inbox.append(ptrs[2])
+        except Exception as e:
+            error = f"rank {self.rank}: {e!r}"
+        errors = [e for e in comm.all_gather_object(error) if e]
+        if errors:
+            raise RuntimeError("asynchronous shards: peer-mapped HBM is unavailable (" + "; ".join(errors) +
+                               "); the device shards need all ranks on one node with peer access")
         self.status = torch.zeros(40, dtype=torch.int64).pin_memory()
         self._st = self.status.numpy()
         timeout = int(min(push_timeout_s, 20.0) * self.TICKS_PER_SECOND)

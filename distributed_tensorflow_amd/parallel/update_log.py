@@ -121,7 +121,11 @@ class HostUpdateLog:
         """Runs the replica's forward + backward pass; with `abortable` the backward pass polls the
         abort word at every layer and stops (zeros for the layers not reached) once the update it
         works for is complete. Returns False when it was cut short."""
-        return replica.forward_backward(should_abort=self.abort_requested if abortable else None)
+        done = replica.forward_backward(should_abort=self.abort_requested if abortable else None)
+        # a GPU replica only enqueues the pass on its own stream; this log stages the gradient with
+        # host-side copies, which must not start before the pass has finished (no-op on CPU replicas)
+        replica.synchronize()
+        return done
 
     def abort_requested(self) -> bool:
         """True once the update this replica is computing a gradient for has all it will take."""
@@ -306,7 +310,13 @@ def make_update_log(replica, comm, board, start_version: int = 0, timeout_s: flo
     one kernel per step for GPU replicas."""
     name = "ulog_" + board.name.strip("/")
     if getattr(replica, "device", None) is not None and replica.device.type == "cuda":
-        from .update_log_hip import DeviceUpdateLog
+        from .update_log_hip import DeviceLogUnavailable, DeviceUpdateLog
 
-        return DeviceUpdateLog(replica, comm, board, name, timeout_s=timeout_s, start_version=start_version)
+        try:
+            return DeviceUpdateLog(replica, comm, board, name, timeout_s=timeout_s, start_version=start_version)
+        except DeviceLogUnavailable as e:
+            # raised on all ranks together: the host log carries the same protocol through the board
+            import logging
+
+            logging.getLogger("dtf").warning("device update log unavailable (%s): using the host update log", e)
     return HostUpdateLog(replica, comm, board, name, timeout_s=timeout_s, start_version=start_version)

@@ -18,6 +18,7 @@ otherwise the numbers are those of the newest finished launch and `stale` says s
 """
 from __future__ import annotations
 
+import os
 import threading
 import time
 from typing import List, Optional
@@ -54,6 +55,10 @@ def abort_words(block: int):
     h = nv.hip()
     wb = int(h.ULOG_WORD_BYTES)
     return block + int(h.UW_ABORT) * wb, block + int(h.UW_VERSION) * wb
+
+
+class DeviceLogUnavailable(RuntimeError):
+    """Raised on EVERY rank when some rank could not map a peer's buffers."""
 
 
 class DeviceUpdateLog:
@@ -96,15 +101,29 @@ class DeviceUpdateLog:
         self._stage: List[int] = []
         self._red: List[int] = []
         self._imported: List[int] = []
-        for r, hs in enumerate(handles):
-            if r == self.rank:
-                ptrs = (self._own_ctl, self._own_stage, self._own_red)
-            else:
-                ptrs = tuple(int(h.ipc_import(x)) for x in hs)
-                self._imported += list(ptrs)
-            self._ctl.append(ptrs[0])
-            self._stage.append(ptrs[1])
-            self._red.append(ptrs[2])
+        # Mapping a peer's HBM can fail (ranks on different nodes, a GPU pair without peer access):
+        # the ranks agree on the outcome, so that either all of them use this log or none does.
+        error = None
+        try:
+            if os.environ.get("DTF_ULOG_FAIL_IMPORT") == str(self.rank):   # test hook: this rank cannot map its peers
+                raise RuntimeError("peer mapping disabled by DTF_ULOG_FAIL_IMPORT")
+            for r, hs in enumerate(handles):
+                if r == self.rank:
+                    ptrs = (self._own_ctl, self._own_stage, self._own_red)
+                else:
+                    ptrs = []
+                    for x in hs:
+                        ptrs.append(int(h.ipc_import(x)))
+                        self._imported.append(ptrs[-1])
+                self._ctl.append(ptrs[0])
+                self._stage.append(ptrs[1])
+                self._red.append(ptrs[2])
+        except Exception as e:   # reported below, on every rank
+            error = f"rank {self.rank}: {e!r}"
+        errors = [e for e in comm.all_gather_object(error) if e]
+        if errors:
+            self.close()
+            raise DeviceLogUnavailable("; ".join(errors))
         self.status = torch.zeros(8, dtype=torch.int64).pin_memory()
         self.status[US_VERSION] = int(start_version)
         self.close_status = torch.zeros(8, dtype=torch.int64).pin_memory()

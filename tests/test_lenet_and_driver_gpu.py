@@ -195,12 +195,13 @@ def test_async_parameter_shards_in_hbm_over_ipc():
     assert out[0]["losses"][-1] < out[0]["losses"][0]
 
 
-@pytest.mark.parametrize("mode", ["backup", "backup_unsynced", "interval", "async", "soft_kill"])
+@pytest.mark.parametrize("mode", ["backup", "backup_unsynced", "interval", "async", "soft_kill", "backup_host_fallback"])
 def test_driver_runs_the_straggler_policies_on_the_device_update_log(tmp_path, mode):
     """Entry script -> driver -> policy, two workers sharing GPU 0 (gloo carries the set-up exchange, the
     aggregation itself runs in kernels over IPC-mapped HBM): both reach max_steps, the chief's
     checkpoint carries the final global step and worker 1 (slowed down) is the one whose gradients
-    are dropped in backup mode."""
+    are dropped in backup mode. backup_host_fallback: rank 1 cannot map its peer's buffers; both ranks
+    must notice together and run the same protocol through the host update log."""
     import json
 
     from distributed_tensorflow_amd.checkpoint.saver import latest_checkpoint, read_bundle
@@ -212,11 +213,15 @@ def test_driver_runs_the_straggler_policies_on_the_device_update_log(tmp_path, m
              "backup_unsynced": ["--backup_worker_method=true", "--num_replicas_to_aggregate=1", "--log_every=4"],
              "interval": ["--interval_method=true", "--interval_ms=3"],
              "async": ["--async_method=true", "--staleness_bound=8"],
-             "soft_kill": ["--soft_kill_method=true", "--should_stop_worker_num=1"]}[mode]
+             "soft_kill": ["--soft_kill_method=true", "--should_stop_worker_num=1"],
+             "backup_host_fallback": ["--backup_worker_method=true", "--num_replicas_to_aggregate=1"]}[mode]
     port = free_port()
     procs, logs = [], []
+    base_env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if mode == "backup_host_fallback":
+        base_env["DTF_ULOG_FAIL_IMPORT"] = "1"
     for r in range(2):
-        env = rank_environment(r, 2, port, 1, dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        env = rank_environment(r, 2, port, 1, base_env)
         logf = open(os.path.join(d, f"rank{r}.log"), "w")
         logs.append(logf)
         procs.append(subprocess.Popen(
@@ -248,6 +253,8 @@ def test_driver_runs_the_straggler_policies_on_the_device_update_log(tmp_path, m
     if mode == "backup":
         by_rank = {r["rank"]: r for r in results}
         assert by_rank[1]["excluded_steps"] > by_rank[0]["excluded_steps"]
+    if mode == "backup_host_fallback":
+        assert all("using the host update log" in o for o in out), (out[0][-1500:], out[1][-1500:])
 
 
 def test_backup_workers_go_on_when_a_gpu_worker_is_killed(tmp_path):
