@@ -40,15 +40,26 @@ class P2PAllReduce:
         self._xbuf: List[int] = []
         self._flags: List[int] = []
         self._imported: List[int] = []
-        for r, (hx, hf) in enumerate(handles):
-            if r == self.rank:
-                self._xbuf.append(self._own_x)
-                self._flags.append(self._own_f)
-            else:
-                px, pf = h.ipc_import(hx), h.ipc_import(hf)
-                self._imported += [px, pf]
-                self._xbuf.append(px)
-                self._flags.append(pf)
+        error = None
+        try:
+            for r, (hx, hf) in enumerate(handles):
+                if r == self.rank:
+                    self._xbuf.append(self._own_x)
+                    self._flags.append(self._own_f)
+                else:
+                    px = h.ipc_import(hx)
+                    self._imported.append(px)
+                    pf = h.ipc_import(hf)
+                    self._imported.append(pf)
+                    self._xbuf.append(px)
+                    self._flags.append(pf)
+        except Exception as e:
+            error = f"rank {self.rank}: {e!r}"
+        # every rank learns whether all of them could map their peers: nobody is left in a collective
+        errors = [e for e in comm.all_gather_object(error) if e]
+        if errors:
+            raise RuntimeError("peer-to-peer all-reduce: peer HBM cannot be mapped (" + "; ".join(errors) +
+                               "); it needs all ranks on one node with peer access - use the RCCL all-reduce")
         self.error = torch.zeros(4, device=comm.device, dtype=torch.int32)
         comm.barrier()
 
