@@ -21,15 +21,13 @@ def main():
             out = {}
             for graph in (True, False):
                 for t in range(1, 11):
-                    step.set_hyper(lr_t=ref.adam_lr_t(1e-3, t))
-                    step.set_step_counter(t)
+                    step.set_hyper(lr_t=ref.adam_lr_t(1e-3, t), step=t)
                     step.run(graph=graph)
                 s.synchronize()
                 t0 = time.perf_counter()
                 n = 100
                 for t in range(11, 11 + n):
-                    step.set_hyper(lr_t=ref.adam_lr_t(1e-3, t))
-                    step.set_step_counter(t)
+                    step.set_hyper(lr_t=ref.adam_lr_t(1e-3, t), step=t)
                     step.run(graph=graph)
                 s.synchronize()
                 out[graph] = (time.perf_counter() - t0) / n

@@ -15,8 +15,7 @@ with torch.cuda.stream(s):
     step = LeNetHipStep(b)
     step.load_batch(torch.rand(b, 28, 28, 1, device="cuda") - 0.5, torch.randint(0, 10, (b,), device="cuda"))
     for t in range(1, 9):
-        step.set_hyper(lr_t=ref.adam_lr_t(1e-3, t))
-        step.set_step_counter(t)
+        step.set_hyper(lr_t=ref.adam_lr_t(1e-3, t), step=t)
         step.run(graph=False)
     s.synchronize()
 print("loss", step.loss_value())

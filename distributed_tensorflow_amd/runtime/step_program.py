@@ -7,7 +7,7 @@ buffer of step-dependent scalars, the scalar outputs (loss, top-1 count), and th
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -60,11 +60,17 @@ class StepProgramBase:
 
     # ------------------------------------------------------------------------------------------
     def set_hyper(self, lr_t: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
-                  grad_scale: float = 1.0, momentum: float = 0.9, weight_decay: float = 0.0) -> None:
+                  grad_scale: float = 1.0, momentum: float = 0.9, weight_decay: float = 0.0,
+                  step: Optional[int] = None) -> None:
         """Writes the step-dependent scalars in stream order, before the next replay. The values
         ride in the launch itself: the host may run any number of steps ahead of the GPU without
-        one step's values leaking into another's (a shared pinned staging buffer would allow that)."""
-        nv.set_scalars(self.hyper, (lr_t, beta1, beta2, eps, grad_scale, momentum, weight_decay))
+        one step's values leaking into another's (a shared pinned staging buffer would allow that).
+        step: also sets the device-visible step number (see set_step_counter) in the same launch."""
+        values = (lr_t, beta1, beta2, eps, grad_scale, momentum, weight_decay)
+        if step is None:
+            nv.set_scalars(self.hyper, values)
+        else:
+            nv.set_scalars(self.hyper, values, u_dst=self.step_counter, u_values=(int(step) * (1 << 20),))
 
     def set_step_counter(self, step: int) -> None:
         """Device-visible step number (dropout draws a fresh mask per step from it)."""

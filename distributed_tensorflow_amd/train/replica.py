@@ -195,6 +195,7 @@ class HipReplica(ReplicaBase):
         self.arena.initialize(seed)
         self.stream = torch.cuda.Stream()
         self._eval_steps = {}
+        self._device_step = -1      # step number last written to the step program's device counter
         self.ctl_block = 0
         self.step = None
         self.use_graph = False
@@ -255,7 +256,11 @@ class HipReplica(ReplicaBase):
         self.last_aborted = False
         nseg = st.num_segments
         with torch.cuda.stream(self.stream):
-            st.set_step_counter(self.updates_applied)
+            # the optimizer launch of the previous update normally left the step number on the device
+            # already (apply_update); a restore or an update applied by the update log's kernels did not
+            if self._device_step != self.updates_applied:
+                st.set_step_counter(self.updates_applied)
+                self._device_step = self.updates_applied
             for i in range(nseg - 1):
                 self._run_segment(i)
                 if on_bucket is not None:
@@ -274,9 +279,11 @@ class HipReplica(ReplicaBase):
         st = self.step
         with torch.cuda.stream(self.stream):
             lr_t = self.adam_lr_t(lr) if self.optimizer == "adam" else lr
-            st.set_hyper(lr_t=lr_t, grad_scale=grad_scale, momentum=self.momentum, weight_decay=self.weight_decay)
+            st.set_hyper(lr_t=lr_t, grad_scale=grad_scale, momentum=self.momentum, weight_decay=self.weight_decay,
+                         step=self.updates_applied + 1)
             self._run_segment(st.num_segments - 1)
         self.updates_applied += 1
+        self._device_step = self.updates_applied
 
     def apply_update_shard(self, lr: float, grad_scale: float, lo: int, hi: int) -> None:
         """Fused optimizer launch over the flat range [lo, hi) only (sharded-optimizer mode)."""
@@ -285,7 +292,8 @@ class HipReplica(ReplicaBase):
         st, a = self.step, self.arena
         with torch.cuda.stream(self.stream):
             lr_t = self.adam_lr_t(lr) if self.optimizer == "adam" else lr
-            st.set_hyper(lr_t=lr_t, grad_scale=grad_scale, momentum=self.momentum, weight_decay=self.weight_decay)
+            st.set_hyper(lr_t=lr_t, grad_scale=grad_scale, momentum=self.momentum, weight_decay=self.weight_decay,
+                         step=self.updates_applied + 1)
             if hi > lo:
                 p, g, m = a.full("params")[lo:hi], a.full("grads")[lo:hi], a.full("slot:m")[lo:hi]
                 if self.optimizer == "adam":
@@ -293,6 +301,7 @@ class HipReplica(ReplicaBase):
                 else:
                     nv.fused_momentum_sgd(p, g, m, st.hyper)
         self.updates_applied += 1
+        self._device_step = self.updates_applied
 
     def zero_grads(self) -> None:
         with torch.cuda.stream(self.stream):
