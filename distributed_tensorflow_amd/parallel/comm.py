@@ -41,10 +41,18 @@ def device_identity(device: torch.device) -> str:
     if device.type != "cuda":
         return "%s/cpu" % socket.gethostname()
     p = torch.cuda.get_device_properties(device)
-    ident = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+    pci = (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+    ident = "%04x:%02x:%02x" % pci
     uuid = getattr(p, "uuid", None)
-    if uuid is not None and str(uuid).strip("0-") != "":
+    has_uuid = uuid is not None and str(uuid).strip("0-") != ""
+    if has_uuid:
         ident += "/" + str(uuid)
+    if not has_uuid and not any(pci):
+        # a driver that reports neither: fall back to what the process was told to use, so that the
+        # GPUs of a node are never mistaken for one device (ranks that share a GPU for a rehearsal
+        # run with the same visibility mask and the same index, and still compare equal)
+        masks = ",".join("%s=%s" % (k, os.environ.get(k, "")) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+        ident += "/%s/index%d" % (masks, device.index if device.index is not None else torch.cuda.current_device())
     return "%s/%s" % (socket.gethostname(), ident)
 
 
