@@ -251,6 +251,9 @@ def define_extension_flags() -> None:
     DEFINE_integer("collective_timeout_s", 600, "Watchdog timeout of collectives and barriers")
     DEFINE_string("comm_backend", "", "torch.distributed backend (default: nccl = RCCL for GPU replicas, gloo for CPU); "
                   "gloo lets several GPU replicas share one device for rehearsals")
+    DEFINE_string("control_plane", "auto", "Where the workers coordinate: shm (shared-memory board, one node), store (the process "
+                  "group's key-value store: workers on several machines, gradients of the straggler policies travel through "
+                  "it), auto (store when the ranks span machines)")
     DEFINE_float("liveness_timeout_s", 0.0, "A worker silent for this long is declared dead (0: collective_timeout_s / 4)")
     DEFINE_integer("eval_batch_size", 0, "Evaluator batch size; 0 = the whole validation set as one batch, like the reference")
     DEFINE_integer("max_evals", 0, "Evaluator: stop after this many evaluated checkpoints (0 = unbounded)")

@@ -32,11 +32,20 @@ def board_name_for(train_dir: str, port: int) -> str:
     return f"dtf_{base}_{port}_{os.getuid()}"
 
 
-def open_board(name: str, world: int, rank: int, nonce: int = 0):
+def open_board(name: str, world: int, rank: int, nonce: int = 0, kind: Optional[str] = None):
     """Rank 0 creates the segment, the others attach. With a nonce (any value all ranks of THIS run
-    agree on) an attacher ignores a segment of the same name left behind by an earlier run."""
+    agree on) an attacher ignores a segment of the same name left behind by an earlier run.
+    kind "store" (or DTF_CONTROL_PLANE=store): the same interface over the process group's key-value
+    store, for workers on several machines (parallel/store_board.py)."""
     from .. import _host
 
+    kind = kind or os.environ.get("DTF_CONTROL_PLANE", "shm")
+    if kind == "store":
+        from .store_board import StoreBoard, default_store
+
+        return StoreBoard(default_store(), "%s_%x" % (name, nonce), world, rank)
+    if kind != "shm":
+        raise ValueError("control plane must be shm or store")
     return _host.Board(name, world, rank == 0, nonce)
 
 

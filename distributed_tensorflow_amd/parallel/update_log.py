@@ -71,6 +71,52 @@ def owner_ranges(total: int, owners: int) -> List[Tuple[int, int, int]]:
     return out
 
 
+class ShmPlane:
+    """Data regions of the host update log in /dev/shm: every replica creates its own staging
+    vector and ring of reduced vectors, then maps everybody's."""
+
+    def __init__(self, name: str, rank: int, world: int, total: int, ring: int):
+        self._name, self.rank, self.world, self.total, self.ring = name, rank, world, total, ring
+        self._files = [f"{name}_stage_{rank}", f"{name}_red_{rank}"]
+        _shm_tensor(self._files[0], total, True)
+        _shm_tensor(self._files[1], total * ring, True)
+        self.stage: List[torch.Tensor] = []
+        self.red: List[torch.Tensor] = []
+
+    def map_all(self) -> None:
+        self.stage = [_shm_tensor(f"{self._name}_stage_{r}", self.total, False) for r in range(self.world)]
+        self.red = [_shm_tensor(f"{self._name}_red_{r}", self.total * self.ring, False).view(self.ring, self.total)
+                    for r in range(self.world)]
+
+    def stage_put(self, grads: torch.Tensor, weight: float = 1.0, accumulate: bool = False) -> None:
+        st = self.stage[self.rank]
+        if accumulate:
+            st.add_(grads.detach().to("cpu") if weight == 1.0 else grads.detach().to("cpu") * weight)
+        elif weight == 1.0:
+            st.copy_(grads)
+        elif grads.is_cuda:
+            st.copy_(grads * weight)
+        else:
+            torch.mul(grads, weight, out=st)
+
+    def stage_get(self, q: int, lo: int, hi: int) -> torch.Tensor:
+        return self.stage[q][lo:hi]
+
+    def red_put(self, slot: int, lo: int, hi: int, t: torch.Tensor, owner: Optional[int] = None) -> None:
+        self.red[self.rank if owner is None else owner][slot][lo:hi].copy_(t)
+
+    def red_get(self, r: int, slot: int, lo: int, hi: int) -> torch.Tensor:
+        return self.red[r][slot][lo:hi]
+
+    def close(self) -> None:
+        for f in self._files:
+            try:
+                os.unlink(os.path.join("/dev/shm", f))
+            except OSError:
+                pass
+        self._files = []
+
+
 def lr_at(lr: LrLike, update: int) -> float:
     return float(lr(update)) if callable(lr) else float(lr)
 
@@ -104,16 +150,18 @@ class HostUpdateLog:
         self.contributed = 0
         self.max_version = 1 << 60
         self._last_lr: LrLike = 0.0
-        # data regions: every replica creates its own, then maps everybody's
-        self._files = [f"{self._name}_stage_{self.rank}", f"{self._name}_red_{self.rank}"]
-        _shm_tensor(self._files[0], self.total, True)
-        _shm_tensor(self._files[1], self.total * self.ring, True)
+        # data regions: shared memory on one node, values of the job's key-value store across machines
+        from .store_board import StoreBoard, StorePlane
+
+        if isinstance(board, StoreBoard):
+            self.plane = StorePlane(board, self._name, self.rank, self.world, self.total, self.ring)
+        else:
+            self.plane = ShmPlane(self._name, self.rank, self.world, self.total, self.ring)
         if comm.is_chief:
             board.agg_reset(start_version)
         comm.barrier()
-        self.stage = [_shm_tensor(f"{self._name}_stage_{r}", self.total, False) for r in range(self.world)]
-        self.red = [_shm_tensor(f"{self._name}_red_{r}", self.total * self.ring, False).view(self.ring, self.total)
-                    for r in range(self.world)]
+        if isinstance(self.plane, ShmPlane):
+            self.plane.map_all()
         comm.barrier()
 
     # ---------------------------------------------------------------------------------------------
@@ -160,11 +208,7 @@ class HostUpdateLog:
         if e >= self.max_version:                     # the run is over: nothing is offered any more
             return ContributionResult(False, -1, self.catch_up(lr), self.version)
         self._throttle(e)
-        st = self.stage[self.rank]
-        if weight == 1.0:
-            st.copy_(a.grads)
-        else:
-            torch.mul(a.grads, weight, out=st)
+        self.plane.stage_put(a.grads, weight)
         status, order, _closed, _open_u = self.board.agg_arrive(e, self.rank, 1, quorum, abort_at, scale, False)
         accepted = status == 0
         if accepted:
@@ -189,21 +233,20 @@ class HostUpdateLog:
         a = self.replica.arena
         b = self.board
         with self._lock:
-            st = self.stage[self.rank]
             count = 1
             if self._pending is not None:
                 pu, pc = self._pending
                 if b.agg_take_back(pu, self.rank, pc):
-                    st.add_(a.grads)              # window still open: nobody reads the staged sum
+                    self.plane.stage_put(a.grads, accumulate=True)   # window still open: nobody reads the staged sum
                     count = pc + 1
                 else:
                     # the window closed with the staged sum in it: the chief may still be reading
                     self._check(b.agg_wait_closed(pu, self.timeout_s), f"update {pu} to close")
                     ent = b.agg_entry(pu)
                     self._check(b.agg_wait_ready(pu, ent[2], self.timeout_s), f"update {pu} to be reduced")
-                    st.copy_(a.grads)
+                    self.plane.stage_put(a.grads)
             else:
-                st.copy_(a.grads)
+                self.plane.stage_put(a.grads)
             open_u = b.agg_open_update()
             if (max_staleness >= 0 and open_u - self.version > max_staleness) or open_u >= self.max_version:
                 self._pending = None
@@ -229,17 +272,18 @@ class HostUpdateLog:
         if u < 0:
             return -1
         count, mask, owners, _scale = b.agg_entry(u)
-        out = self.red[self.rank][u % self.ring]
-        first = True
-        for q in range(self.world):
-            if (mask >> q) & 1:
-                if first:
-                    out.copy_(self.stage[q])
-                    first = False
-                else:
-                    out.add_(self.stage[q])
+        self.plane.red_put(u % self.ring, 0, self.total, self._sum_staged(mask, 0, self.total))
         b.agg_publish_ready(u, self.rank)
         return u
+
+    def _sum_staged(self, mask: int, lo: int, hi: int) -> torch.Tensor:
+        """Sum over the contributors in `mask` of their staged gradients' [lo, hi)."""
+        acc = None
+        for q in range(self.world):
+            if (mask >> q) & 1:
+                part = self.plane.stage_get(q, lo, hi)
+                acc = part.clone() if acc is None else acc.add_(part)
+        return acc if acc is not None else torch.zeros(hi - lo)
 
     # ---------------------------------------------------------------------------------------------
     def catch_up(self, lr: LrLike, reduce_own: bool = True) -> int:
@@ -262,26 +306,38 @@ class HostUpdateLog:
                 for r, lo, hi in shards:
                     if r != self.rank or hi <= lo:
                         continue
-                    out = self.red[self.rank][slot][lo:hi]
-                    first = True
-                    for q in range(self.world):
-                        if (mask >> q) & 1:
-                            if first:
-                                out.copy_(self.stage[q][lo:hi])
-                                first = False
-                            else:
-                                out.add_(self.stage[q][lo:hi])
+                    self.plane.red_put(slot, lo, hi, self._sum_staged(mask, lo, hi))
                 b.agg_publish_ready(u, self.rank)
-            self._check(b.agg_wait_ready(u, owners, self.timeout_s), f"the reduced shards of update {u}")
+            self._wait_shards(u, mask, owners, shards)
             g = a.grads
             for r, lo, hi in shards:
                 if hi > lo:
-                    g[lo:hi].copy_(self.red[r][slot][lo:hi])
+                    g[lo:hi].copy_(self.plane.red_get(r, slot, lo, hi))
             self.replica.updates_applied = u
             self.replica.apply_update(lr_at(lr, u), grad_scale=scale)
             self.version = u + 1
             b.agg_set_applied(self.rank, self.version)
             n += 1
+
+    def _wait_shards(self, u: int, mask: int, owners: int, shards) -> None:
+        """Waits for the owners' reduced shards of update u. An owner the watchdog has declared dead
+        will never publish its shard: the lowest-ranked live contributor sums it in its place from the
+        staged gradients (a dead worker's staged gradient outlives it) into the dead owner's region
+        and publishes it in the dead owner's name."""
+        b = self.board
+        deadline = time.time() + self.timeout_s
+        while True:
+            if b.agg_wait_ready(u, owners, min(0.5, max(0.01, deadline - time.time()))):
+                return
+            dead = int(b.agg_dead())
+            live = [q for q in range(self.world) if (mask >> q) & 1 and not (dead >> q) & 1]
+            if owners & dead and live and live[0] == self.rank:
+                for r, lo, hi in shards:
+                    if (dead >> r) & 1 and not b.agg_is_ready(u, r):
+                        if hi > lo:
+                            self.plane.red_put(u % self.ring, lo, hi, self._sum_staged(mask, lo, hi), owner=r)
+                        b.agg_publish_ready(u, r)
+            self._check(time.time() < deadline and not b.should_stop(), f"the reduced shards of update {u}")
 
     def finish(self, final_version: Optional[int] = None, collective: bool = True) -> None:
         """End of training: a replica may stop contributing while others still need its published
@@ -297,18 +353,19 @@ class HostUpdateLog:
             time.sleep(0.001)
 
     def close(self) -> None:
-        for f in self._files:
-            try:
-                os.unlink(os.path.join("/dev/shm", f))
-            except OSError:
-                pass
-        self._files = []
+        self.plane.close()
 
 
 def make_update_log(replica, comm, board, start_version: int = 0, timeout_s: float = 600.0):
     """The update log that matches the replica: host memory for CPU replicas, peer-mapped HBM and
     one kernel per step for GPU replicas."""
     name = "ulog_" + board.name.strip("/")
+    from .store_board import StoreBoard
+
+    if isinstance(board, StoreBoard):
+        # workers on several machines: gradients are staged through the host and the store, whatever
+        # device computed them
+        return HostUpdateLog(replica, comm, board, name, timeout_s=timeout_s, start_version=start_version)
     if getattr(replica, "device", None) is not None and replica.device.type == "cuda":
         from .update_log_hip import DeviceLogUnavailable, DeviceUpdateLog
 

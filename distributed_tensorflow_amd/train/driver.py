@@ -142,27 +142,44 @@ def train(flags, model: str) -> Dict:
     if is_chief:
         os.makedirs(train_dir, exist_ok=True)
 
-    # ---- control board (single-node control plane)
+    # ---- control board
+    # One node: POSIX shared memory (csrc/host/board.cc), and the update log / asynchronous shards map
+    # peers' memory. Ranks on several machines: the same board interface over the process group's
+    # key-value store (parallel/store_board.py), with the host update log's regions as store values -
+    # the straggler policies then work across machines the way the reference's do through its
+    # parameter server. What still needs one node: the asynchronous shards and the sharded
+    # optimizer's checkpoint rendezvous (both move data through mapped memory).
     needs_board = world > 1
-    # The board is POSIX shared memory, and the update log / asynchronous shards map peers' HBM:
-    # both end at the node. Plain synchronous training only needs the process group, so it also
-    # runs over several nodes (RCCL across them), without the board's extras (liveness watchdog,
-    # worker-time telemetry).
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    if world > 1 and local_world < world:
-        needs_one_node = [f for f in ("interval_method", "soft_kill_method", "backup_worker_method", "weighted_grads_method",
-                                      "async_method", "worker_times_cdf_method", "reduce_scatter") if getattr(flags, f, False)]
+    spans_machines = world > 1 and local_world < world
+    plane = getattr(flags, "control_plane", "auto") or "auto"
+    if plane == "auto":
+        plane = os.environ.get("DTF_CONTROL_PLANE") or ("store" if spans_machines else "shm")
+    if plane not in ("shm", "store"):
+        raise ValueError("--control_plane must be auto, shm or store")
+    if spans_machines and plane == "shm":
+        raise ValueError(f"{world} ranks over machines of {local_world}: the shared-memory control board ends at the machine; "
+                         "use --control_plane=store (or auto)")
+    if world > 1 and plane == "store":
+        needs_one_node = [f for f in ("async_method", "reduce_scatter") if getattr(flags, f, False)]
         if needs_one_node:
-            raise ValueError(f"{world} ranks over nodes of {local_world}: --{needs_one_node[0]} coordinates through shared memory "
-                             "and peer-mapped HBM and runs within one node; only plain synchronous training spans nodes")
-        log.info("Worker %d: %d ranks span several nodes (%d per node): synchronous all-reduce over the process group, "
-                 "no shared-memory control board", rank, world, local_world)
-        needs_board = False
+            raise ValueError(f"--{needs_one_node[0]} moves data through mapped memory and runs within one machine "
+                             "(--control_plane=shm); the other aggregation policies run over the store")
+        if world > 16:
+            wants_log = [f for f in ("interval_method", "soft_kill_method", "backup_worker_method", "weighted_grads_method",
+                                     "worker_times_cdf_method") if getattr(flags, f, False)]
+            if wants_log:
+                raise ValueError(f"--{wants_log[0]} over the store-backed control board serves at most 16 workers")
+            # plain synchronous training only needs the process group
+            log.info("Worker %d: %d ranks: synchronous all-reduce over the process group, no control board", rank, world)
+            needs_board = False
+        else:
+            log.info("Worker %d: %d ranks coordinate through the process group's key-value store", rank, world)
     board = None
     if needs_board:
         name = flags.board_name or control_plane.board_name_for(train_dir, task.master_port)
-        board = control_plane.open_board(name, world, rank, control_plane.run_nonce(comm))
-        if is_chief:
+        board = control_plane.open_board(name, world, rank, control_plane.run_nonce(comm), kind=plane)
+        if is_chief and plane == "shm":
             control_plane.unlink_on_sigterm(name)
 
     # ---- data

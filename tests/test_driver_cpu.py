@@ -258,17 +258,22 @@ def _wait_for_step(path, step, timeout=120):
     return False
 
 
-@pytest.mark.parametrize("mode", ["sync", "backup"])
+@pytest.mark.parametrize("mode", ["sync", "backup", "backup_store"])
 def test_a_killed_worker_is_noticed_by_name(tmp_path, mode):
     """Three workers, worker 2 is SIGKILLed mid-run. Full sync cannot go on: the survivors stop within
     the liveness bound, non-zero, naming worker 2 (not after the process group's 600 s). Backup
-    workers with M = 2 of 3 finish their steps without it."""
+    workers with M = 2 of 3 finish their steps without it - also when they coordinate through the
+    process group's key-value store instead of shared memory (backup_store)."""
     import signal
 
     from distributed_tensorflow_amd.launch import free_port
 
     d = str(tmp_path)
     extra = ["--max_steps=100000"] if mode == "sync" else ["--max_steps=120", "--backup_worker_method=true", "--num_replicas_to_aggregate=2"]
+    if mode == "backup_store":
+        # heartbeats queue behind the gradients in the store's single server thread: a silence bound
+        # of 2 s is too tight for 13 MB gradients on a loaded test machine
+        extra += ["--control_plane=store", "--liveness_timeout_s=8"]
     procs, logs = _start_ranks(3, extra, d, free_port())
     try:
         assert _wait_for_step(os.path.join(d, "rank2.log"), 3), open(os.path.join(d, "rank2.log")).read()[-2000:]
@@ -296,12 +301,15 @@ def test_a_killed_worker_is_noticed_by_name(tmp_path, mode):
         assert steps[-1] >= 120
 
 
-def test_plain_sync_spans_nodes_without_the_board_and_policies_refuse(tmp_path):
-    """LOCAL_WORLD_SIZE < WORLD_SIZE means the ranks sit on several nodes: full sync runs through
-    the process group alone; a policy that needs shared memory says so and stops."""
+def test_ranks_on_several_machines_coordinate_through_the_store(tmp_path):
+    """LOCAL_WORLD_SIZE < WORLD_SIZE means the ranks sit on several machines: the control board and
+    the update log's regions then live in the process group's key-value store. Full sync trains,
+    backup workers (1 of 2, worker 1 slowed down) and the timer-driven interval mode reach max_steps
+    with the chief's checkpoint at the final step; what moves data through mapped memory refuses."""
+    from distributed_tensorflow_amd.checkpoint.saver import latest_checkpoint, read_bundle
     from distributed_tensorflow_amd.launch import free_port, rank_environment
 
-    def run(extra, sub):
+    def run(extra, sub, steps=5):
         d = str(tmp_path / sub)
         os.makedirs(d)
         port = free_port()
@@ -312,15 +320,28 @@ def test_plain_sync_spans_nodes_without_the_board_and_policies_refuse(tmp_path):
             env["LOCAL_RANK"] = "0"
             procs.append(subprocess.Popen(
                 [sys.executable, "DistributedLeNet/src/mnist_distributed_train.py", "--synthetic_data", "--device=cpu", "--batch_size=8",
-                 f"--train_dir={d}", "--max_steps=5", "--save_interval_secs=100000"] + extra,
+                 f"--train_dir={d}", f"--max_steps={steps}", "--save_interval_secs=100000"] + extra,
                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=ROOT))
-        outs = [p.communicate(timeout=200)[0] for p in procs]
-        return [p.returncode for p in procs], outs
+        outs = [p.communicate(timeout=300)[0] for p in procs]
+        return [p.returncode for p in procs], outs, d
 
-    rcs, outs = run([], "sync")
+    rcs, outs, _ = run([], "sync")
     assert rcs == [0, 0], outs[0][-2000:]
-    assert all("span several nodes" in o for o in outs)
+    assert all("key-value store" in o for o in outs)
     steps = [int(m.group(2)) for m in (TRAIN_RE.match(l) for l in outs[1].splitlines()) if m]
     assert steps == list(range(1, 6))
-    rcs, outs = run(["--backup_worker_method=true", "--num_replicas_to_aggregate=1"], "backup")
-    assert all(rc != 0 for rc in rcs) and all("runs within one node" in o for o in outs)
+
+    rcs, outs, d = run(["--backup_worker_method=true", "--num_replicas_to_aggregate=1", "--inject_straggler_ms=20",
+                        "--inject_straggler_ranks=1"], "backup", steps=12)
+    assert rcs == [0, 0], (outs[0][-2000:], outs[1][-2000:])
+    assert "aggregation policy backup over 2 replicas (aggregate 1)" in outs[0]
+    assert int(read_bundle(latest_checkpoint(d))["global_step"]) >= 12
+
+    rcs, outs, d = run(["--interval_method=true", "--interval_ms=20"], "interval", steps=8)
+    assert rcs == [0, 0], (outs[0][-2000:], outs[1][-2000:])
+    assert int(read_bundle(latest_checkpoint(d))["global_step"]) >= 8
+
+    rcs, outs, _ = run(["--async_method=true"], "async")
+    assert all(rc != 0 for rc in rcs) and all("within one machine" in o for o in outs)
+    rcs, outs, _ = run(["--control_plane=shm"], "shm")
+    assert all(rc != 0 for rc in rcs) and all("ends at the machine" in o for o in outs)

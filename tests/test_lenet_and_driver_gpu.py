@@ -195,7 +195,7 @@ def test_async_parameter_shards_in_hbm_over_ipc():
     assert out[0]["losses"][-1] < out[0]["losses"][0]
 
 
-@pytest.mark.parametrize("mode", ["backup", "backup_unsynced", "interval", "async", "soft_kill", "backup_host_fallback"])
+@pytest.mark.parametrize("mode", ["backup", "backup_unsynced", "interval", "async", "soft_kill", "backup_host_fallback", "backup_store"])
 def test_driver_runs_the_straggler_policies_on_the_device_update_log(tmp_path, mode):
     """Entry script -> driver -> policy, two workers sharing GPU 0 (gloo carries the set-up exchange, the
     aggregation itself runs in kernels over IPC-mapped HBM): both reach max_steps, the chief's
@@ -214,7 +214,9 @@ def test_driver_runs_the_straggler_policies_on_the_device_update_log(tmp_path, m
              "interval": ["--interval_method=true", "--interval_ms=3"],
              "async": ["--async_method=true", "--staleness_bound=8"],
              "soft_kill": ["--soft_kill_method=true", "--should_stop_worker_num=1"],
-             "backup_host_fallback": ["--backup_worker_method=true", "--num_replicas_to_aggregate=1"]}[mode]
+             "backup_host_fallback": ["--backup_worker_method=true", "--num_replicas_to_aggregate=1"],
+             # GPU replicas whose workers coordinate as if on different machines: gradients staged through the host and the store
+             "backup_store": ["--backup_worker_method=true", "--num_replicas_to_aggregate=1", "--control_plane=store"]}[mode]
     port = free_port()
     procs, logs = [], []
     base_env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
