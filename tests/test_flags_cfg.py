@@ -120,3 +120,24 @@ def test_default_grad_buckets_follow_the_gradient_size():
     assert default_grad_buckets(size(resnet_param_specs(18))) == 3     # ResNet-110: 6.9 MB
     assert default_grad_buckets(size(lenet_param_specs())) == 3        # LeNet: 13 MB (its program has two segments at most)
     assert default_grad_buckets((4 << 20) // 4) == 1 and default_grad_buckets((4 << 20) // 4 + 1) == 3
+
+
+def test_worker_hosts_on_several_machines_give_local_ranks(monkeypatch):
+    """Reference-style command lines (--worker_hosts=h1:p,h2:p --task_id=K): a task's GPU index is its
+    position among the workers of its own machine, and LOCAL_WORLD_SIZE < WORLD_SIZE tells the driver
+    to coordinate through the process group's store."""
+    import os
+
+    from distributed_tensorflow_amd.cluster import resolve_task
+
+    t = resolve_task("worker", 3, "a:2222", "a:2230,a:2231,b:2230,b:2231,b:2232")
+    assert (t.local_rank, t.local_world, t.num_workers, t.master_addr) == (1, 3, 5, "a")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    t.export()
+    assert os.environ["LOCAL_RANK"] == "1" and os.environ["LOCAL_WORLD_SIZE"] == "3" and os.environ["WORLD_SIZE"] == "5"
+    one = resolve_task("worker", 1, "", "localhost:2230,127.0.0.1:2231")     # two names of one machine
+    assert (one.local_rank, one.local_world) == (1, 2)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    assert resolve_task("ps", 0, "a:2222", "a:2230,b:2230").local_world == -1
