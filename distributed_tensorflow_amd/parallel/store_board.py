@@ -22,7 +22,7 @@ from __future__ import annotations
 import datetime
 import json
 import time
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import torch
 
@@ -416,9 +416,3 @@ def default_store():
     if not dist.is_initialized():
         raise RuntimeError("the store-backed control board needs an initialised process group")
     return distributed_c10d._get_default_store()
-
-
-def hosts_of(comm) -> List[str]:
-    import socket
-
-    return comm.all_gather_object(socket.gethostname())
