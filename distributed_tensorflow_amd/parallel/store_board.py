@@ -369,12 +369,18 @@ class StorePlane:
         for i, lo in enumerate(range(0, max(1, flat.numel()), self._PIECE)):
             self.store.set(self._p + f"{key}/{i}", data[lo:lo + self._PIECE].tobytes())
 
-    def _fetch(self, key: str, numel: int) -> torch.Tensor:
-        keys = [self._p + f"{key}/{i}" for i in range(max(1, -(-numel // self._PIECE)))]
-        data = b"".join(self.store.multi_get(keys))
-        if len(data) != numel * 4:
-            raise RuntimeError(f"update log: region {key} holds {len(data) // 4} values, expected {numel}")
-        return torch.frombuffer(bytearray(data), dtype=torch.float32) if numel else torch.empty(0)
+    def _fetch(self, key: str, numel: int, lo: int = 0, hi: Optional[int] = None) -> torch.Tensor:
+        """Values [lo, hi) of a region of `numel` values: only the pieces that overlap travel."""
+        hi = numel if hi is None else hi
+        if hi <= lo:
+            return torch.empty(0)
+        first, last = lo // self._PIECE, (hi - 1) // self._PIECE
+        data = b"".join(self.store.multi_get([self._p + f"{key}/{i}" for i in range(first, last + 1)]))
+        want = min(numel, (last + 1) * self._PIECE) - first * self._PIECE
+        if len(data) != want * 4:
+            raise RuntimeError(f"update log: region {key} holds {len(data) // 4} values where {want} were expected")
+        t = torch.frombuffer(bytearray(data), dtype=torch.float32)
+        return t[lo - first * self._PIECE:hi - first * self._PIECE]
 
     # staged gradient of this worker
     def stage_put(self, grads: torch.Tensor, weight: float = 1.0, accumulate: bool = False) -> None:
@@ -387,7 +393,7 @@ class StorePlane:
         self._put(f"stage/{self.rank}", self._staged)
 
     def stage_get(self, q: int, lo: int, hi: int) -> torch.Tensor:
-        return self._fetch(f"stage/{q}", self.total)[lo:hi]
+        return self._fetch(f"stage/{q}", self.total, lo, hi)
 
     # reduced shards
     def red_put(self, slot: int, lo: int, hi: int, t: torch.Tensor, owner: Optional[int] = None) -> None:
