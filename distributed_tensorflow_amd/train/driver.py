@@ -147,8 +147,9 @@ def train(flags, model: str) -> Dict:
     # peers' memory. Ranks on several machines: the same board interface over the process group's
     # key-value store (parallel/store_board.py), with the host update log's regions as store values -
     # the straggler policies then work across machines the way the reference's do through its
-    # parameter server. What still needs one node: the asynchronous shards and the sharded
-    # optimizer's checkpoint rendezvous (both move data through mapped memory).
+    # parameter server (the sharded optimizer is collectives plus a checkpoint rendezvous on the board,
+    # so it runs there too). What still needs one node: the asynchronous shards, which move data
+    # through mapped memory.
     needs_board = world > 1
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     spans_machines = world > 1 and local_world < world
@@ -161,9 +162,8 @@ def train(flags, model: str) -> Dict:
         raise ValueError(f"{world} ranks over machines of {local_world}: the shared-memory control board ends at the machine; "
                          "use --control_plane=store (or auto)")
     if world > 1 and plane == "store":
-        needs_one_node = [f for f in ("async_method", "reduce_scatter") if getattr(flags, f, False)]
-        if needs_one_node:
-            raise ValueError(f"--{needs_one_node[0]} moves data through mapped memory and runs within one machine "
+        if flags.async_method:
+            raise ValueError("--async_method moves data through mapped memory and runs within one machine "
                              "(--control_plane=shm); the other aggregation policies run over the store")
         if world > 16:
             wants_log = [f for f in ("interval_method", "soft_kill_method", "backup_worker_method", "weighted_grads_method",

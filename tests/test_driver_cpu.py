@@ -346,6 +346,11 @@ def test_ranks_on_several_machines_coordinate_through_the_store(tmp_path):
     assert rcs == [0, 0], (outs[0][-2000:], outs[1][-2000:])
     assert "ELAPSED TIMES" in outs[0] and "ITERATION TIMES" in outs[0]
 
+    # sharded optimizer: reduce-scatter + all-gather over the process group, checkpoint rendezvous on the store board
+    rcs, outs, d = run(["--reduce_scatter=true", "--save_interval_secs=1"], "sharded", steps=10)
+    assert rcs == [0, 0], (outs[0][-2000:], outs[1][-2000:])
+    assert int(read_bundle(latest_checkpoint(d))["global_step"]) >= 10
+
     rcs, outs, _ = run(["--async_method=true"], "async")
     assert all(rc != 0 for rc in rcs) and all("within one machine" in o for o in outs)
     rcs, outs, _ = run(["--control_plane=shm"], "shm")
