@@ -123,7 +123,7 @@ def test_conv_stem_forward_statistics_and_filter_gradient(b):
     assert float(slots[:, 432:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("b,imgs", [(1, 1), (3, 1), (3, 2), (4, 2), (37, 0), (1030, 0)])
+@pytest.mark.parametrize("b,imgs", [(1, 1), (3, 1), (3, 2), (4, 2), (37, 0), (300, 1), (1030, 0)])
 def test_conv5x5_tile_forward(b, imgs):
     """Whole-image 5x5 kernel (LeNet conv2 shape): bias + ReLU epilogue, odd batches so the last
     tile is partly empty, both images-per-tile variants."""
@@ -155,7 +155,7 @@ def test_conv5x5_filter_gradient(b):
     close(dw2 - 1.0, wt.grad, tol=5e-4)
 
 
-@pytest.mark.parametrize("b,imgs", [(1, 1), (3, 2), (7, 1), (515, 0)])
+@pytest.mark.parametrize("b,imgs", [(1, 1), (3, 2), (7, 1), (300, 1), (515, 0)])
 def test_conv5x5_forward_with_fused_pool(b, imgs):
     x = rnd(b, 14, 14, 32)
     wt = rnd(5, 5, 32, 64, scale=0.05)
