@@ -70,7 +70,7 @@ struct C5 {
   static constexpr int OS = CW + 4;                  // pixel stride of the output tile parked in LDS (fused pool)
   static constexpr int LDS_OUT_FLOATS = PX * OS;
   static constexpr int LDS_FLOATS = LDS_PLANE_FLOATS;
-  static_assert(CW == 32 || CW == 64, "4 waves cover 2 or 4 output-channel tiles");
+  static_assert(CW == 16 || CW == 32 || CW == 64, "4 waves cover 1, 2 or 4 output-channel tiles");
   static_assert(CIN % 16 == 0, "input channels come in groups of 16");
 };
 
@@ -509,9 +509,11 @@ void conv5x5_tile(const Conv5x5Args& a, hipStream_t stream) {
   if (a.Cin == 64 && a.Cout == 32 && a.flip) {
     if (a.pool_dp) {
       if (!a.pool_arg || !a.pool_p) throw std::runtime_error("conv5x5_tile: pooled staging needs dp, arg and p");
+      if (a.B < 256) return launch_c5<64, 32, 1, true, false, true, false, 2>(a, stream);   // fewer images than CUs
       return launch_c5<64, 32, 1, true, false, true>(a, stream);
     }
     if (!a.x) throw std::runtime_error("conv5x5_tile: null input");
+    if (a.B < 256) return launch_c5<64, 32, 1, true, false, false, false, 2>(a, stream);
     return launch_c5<64, 32, 1, true, false>(a, stream);
   }
   throw std::runtime_error("conv5x5_tile: unsupported channel counts / direction");
