@@ -303,9 +303,19 @@ constexpr int kWgYFloats = kImgPx * kWgPsy;
 constexpr int kWgXChunks = kImgPx * 8, kWgYChunks = kImgPx * 16;
 constexpr int kWgNpfX = (kWgXChunks + 255) / 256, kWgNpfY = (kWgYChunks + 255) / 256;
 
-template <bool POOLED>
+// TSPLIT = 2: two workgroups per image, each with its own copy of the staged image and half of the
+// 25 taps (13 and 12) - for batches with fewer images than CUs.
+template <bool POOLED, int TSPLIT>
 __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(Conv5x5WgradArgs a) {
   DTF_ABORT_GUARD(a);
+  constexpr int NTAP = (25 + TSPLIT - 1) / TSPLIT;             // tap slots of this workgroup
+  const int tap0 = TSPLIT > 1 ? (int)blockIdx.y * NTAP : 0;    // its first tap
+  int tap_off[NTAP];                                           // window offset of every tap slot (uniform)
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    const int tap = min(tap0 + t, 24);                         // a slot past the last tap reads tap 24 and is not used
+    tap_off[t] = ((tap / 5) * kPW + tap % 5) * kWgPsx;
+  }
   extern __shared__ __align__(16) float lds[];
   float* sx = lds;
   float* sy = lds + kWgXFloats;
@@ -358,9 +368,9 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(Conv5x5WgradArgs a) 
     }
   };
 
-  floatx4 acc[25][2];
+  floatx4 acc[NTAP][2];
 #pragma unroll
-  for (int t = 0; t < 25; ++t) acc[t][0] = acc[t][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NTAP; ++t) acc[t][0] = acc[t][1] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   int img = blockIdx.x;
   if (img < a.B) fetch(img);
@@ -391,27 +401,32 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(Conv5x5WgradArgs a) 
     // reads of k-step ks + 1 are issued before the 50 MFMAs of k-step ks (two register sets,
     // the loop body handles two k-steps), so no MFMA waits for LDS.
     int px_y = 0, px_x = g;
-    auto load_step = [&](float (&av)[25], float (&bv)[2]) {
+    auto load_step = [&](float (&av)[NTAP], float (&bv)[2]) {
       const float* yrow = sy + (px_y * kHW + px_x) * kWgPsy + 32 * h + n;
       bv[0] = yrow[0];
       bv[1] = yrow[16];
       const float* xwin = sx + (px_y * kPW + px_x) * kWgPsx + 16 * v + n;   // window origin of the pixel
+      if constexpr (TSPLIT == 1) {
 #pragma unroll
-      for (int kh = 0; kh < 5; ++kh)
+        for (int kh = 0; kh < 5; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 5; ++kw) av[kh * 5 + kw] = xwin[(kh * kPW + kw) * kWgPsx];
+          for (int kw = 0; kw < 5; ++kw) av[kh * 5 + kw] = xwin[(kh * kPW + kw) * kWgPsx];   // immediates
+      } else {
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) av[t] = xwin[tap_off[t]];
+      }
       px_x += 4;
       if (px_x >= kHW) { px_x -= kHW; ++px_y; }
     };
-    auto mfma_step = [&](const float (&av)[25], const float (&bv)[2]) {
+    auto mfma_step = [&](const float (&av)[NTAP], const float (&bv)[2]) {
 #pragma unroll
-      for (int t = 0; t < 25; ++t) {
+      for (int t = 0; t < NTAP; ++t) {
         acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[0], acc[t][0], 0, 0, 0);
         acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[1], acc[t][1], 0, 0, 0);
       }
     };
     constexpr int kSteps = kImgPx / 4;   // 49
-    float a0[25], a1[25], b0[2], b1[2];
+    float a0[NTAP], a1[NTAP], b0[2], b1[2];
     load_step(a0, b0);
 #pragma unroll 1
     for (int ks = 0; ks + 2 < kSteps; ks += 2) {
@@ -430,25 +445,31 @@ __global__ __launch_bounds__(256) void conv5x5_wgrad_kernel(Conv5x5WgradArgs a) 
   // lane holds dw[tap][ci = 16v + 4g + i][co = 32h + 16j + n]
   const int lane_off = (16 * v + 4 * g) * 64 + 32 * h + n;
   if (a.partials) {
-    float* dst = a.partials + (size_t)blockIdx.x * (25 * 2048) + lane_off;
+    float* dst = a.partials + (size_t)blockIdx.x * (25 * 2048) + (size_t)tap0 * 2048 + lane_off;
 #pragma unroll
-    for (int t = 0; t < 25; ++t)
+    for (int t = 0; t < NTAP; ++t) {
+      if (tap0 + t < 25) {   // (a break would keep the loop rolled and the accumulators in scratch memory)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dst[t * 2048 + i * 64 + 16 * j] = acc[t][j][i];
+      }
+    }
+    return;
+  }
+  float* dst = a.dw + (a.slot_stride ? (size_t)(blockIdx.x & (kStatSlots - 1)) * a.slot_stride : 0) + (size_t)tap0 * 2048 + lane_off;
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    if (tap0 + t < 25) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dst[t * 2048 + i * 64 + 16 * j] = acc[t][j][i];
-    return;
+        for (int i = 0; i < 4; ++i) {
+          const float s = acc[t][j][i];
+          if (s != 0.f) atomicAdd(dst + t * 2048 + i * 64 + 16 * j, s);
+        }
+    }
   }
-  float* dst = a.dw + (a.slot_stride ? (size_t)(blockIdx.x & (kStatSlots - 1)) * a.slot_stride : 0) + lane_off;
-#pragma unroll
-  for (int t = 0; t < 25; ++t)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float s = acc[t][j][i];
-        if (s != 0.f) atomicAdd(dst + t * 2048 + i * 64 + 16 * j, s);
-      }
 }
 
 // [25][CIN][COUT] (HWIO filter) -> [25][COUT][CIN]
@@ -528,18 +549,25 @@ void conv5x5_wgrad(const Conv5x5WgradArgs& a, hipStream_t stream) {
   if (a.B < 1) throw std::runtime_error("conv5x5_wgrad: empty batch");
   const size_t shmem = (size_t)(kWgXFloats + kWgYFloats) * sizeof(float);
   static const bool once = [&] {
-    ensure_dynamic_lds(reinterpret_cast<const void*>(conv5x5_wgrad_kernel<false>), shmem);
-    ensure_dynamic_lds(reinterpret_cast<const void*>(conv5x5_wgrad_kernel<true>), shmem);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(conv5x5_wgrad_kernel<false, 1>), shmem);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(conv5x5_wgrad_kernel<true, 1>), shmem);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(conv5x5_wgrad_kernel<false, 2>), shmem);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(conv5x5_wgrad_kernel<true, 2>), shmem);
     return true;
   }();
   (void)once;
   const int grid = conv5x5_wgrad_parts(a.B);
+  // fewer images than CUs: two workgroups per image, 13 and 12 of the 25 taps each
+  const bool split = a.B < 256;
+  const dim3 g(grid, split ? 2 : 1);
   if (a.pool_dp) {
     if (!a.pool_arg || !a.pool_p) throw std::runtime_error("conv5x5_wgrad: pooled staging needs dp, arg and p");
-    launch("conv5x5_wgrad", conv5x5_wgrad_kernel<true>, dim3(grid), dim3(256), shmem, stream, a);
+    if (split) launch("conv5x5_wgrad", conv5x5_wgrad_kernel<true, 2>, g, dim3(256), shmem, stream, a);
+    else launch("conv5x5_wgrad", conv5x5_wgrad_kernel<true, 1>, g, dim3(256), shmem, stream, a);
   } else {
     if (!a.dy) throw std::runtime_error("conv5x5_wgrad: null output gradient");
-    launch("conv5x5_wgrad", conv5x5_wgrad_kernel<false>, dim3(grid), dim3(256), shmem, stream, a);
+    if (split) launch("conv5x5_wgrad", conv5x5_wgrad_kernel<false, 2>, g, dim3(256), shmem, stream, a);
+    else launch("conv5x5_wgrad", conv5x5_wgrad_kernel<false, 1>, g, dim3(256), shmem, stream, a);
   }
 }
 
