@@ -71,8 +71,9 @@ __global__ __launch_bounds__(256) void conv1_pool_fwd_kernel(Conv1PoolFwdArgs a)
     __syncthreads();
     const int nxt = img + gridDim.x;
     if (nxt < a.B && tid < kCells) pf = reinterpret_cast<const float4*>(a.x + (size_t)nxt * kIn * kIn)[tid];
+    // gridDim.y > 1 (fewer images than CUs): the workgroups of an image take every gridDim.y-th round
 #pragma unroll 1
-    for (int round = 0; round < kRounds; ++round) {
+    for (int round = blockIdx.y; round < kRounds; round += gridDim.y) {
       const int cell = round * 8 + sub;
       if (cell < kCells) {
         float pt[6][6];
@@ -138,7 +139,9 @@ __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(Conv1PoolBwdArgs a)
       }
     }
   };
-  fetch(img, 0, g_c, p_c, k_c);
+  // gridDim.y > 1 (fewer images than CUs): the workgroups of an image take every gridDim.y-th batch
+  const int batch0 = blockIdx.y, batch_step = gridDim.y;
+  fetch(img, batch0, g_c, p_c, k_c);
   __syncthreads();
   for (int buf = 0; img < a.B; img += gridDim.x, buf ^= 1) {
     if (tid < kCells) stage_image(plane[buf], pf, tid);
@@ -146,9 +149,9 @@ __global__ __launch_bounds__(256) void conv1_pool_bwd_kernel(Conv1PoolBwdArgs a)
     const int nxt = img + gridDim.x;
     if (nxt < a.B && tid < kCells) pf = reinterpret_cast<const float4*>(a.x + (size_t)nxt * kIn * kIn)[tid];
 #pragma unroll 1
-    for (int batch = 0; batch < kBatches; ++batch) {
-      const bool last = batch + 1 == kBatches;
-      fetch(last ? nxt : img, last ? 0 : batch + 1, g_n, p_n, k_n);
+    for (int batch = batch0; batch < kBatches; batch += batch_step) {
+      const bool last = batch + batch_step >= kBatches;
+      fetch(last ? nxt : img, last ? batch0 : batch + batch_step, g_n, p_n, k_n);
 #pragma unroll
       for (int u = 0; u < kBatch; ++u) {
         const int cell = (batch * kBatch + u) * 8 + sub;
@@ -210,7 +213,7 @@ void conv1_pool_fwd(const Conv1PoolFwdArgs& a, hipStream_t stream) {
   static const int bpc = blocks_per_cu(conv1_pool_fwd_kernel);
   const int cap = 256 * bpc;
   const int grid = ceil_div(a.B, ceil_div(a.B, cap));
-  launch("conv1_pool_fwd", conv1_pool_fwd_kernel, dim3(grid), dim3(256), 0, stream, a);
+  launch("conv1_pool_fwd", conv1_pool_fwd_kernel, dim3(grid, a.B < 512 ? 2 : 1), dim3(256), 0, stream, a);
 }
 
 void conv1_pool_bwd(const Conv1PoolBwdArgs& a, hipStream_t stream) {
@@ -219,7 +222,7 @@ void conv1_pool_bwd(const Conv1PoolBwdArgs& a, hipStream_t stream) {
   // fewer, longer blocks than the forward kernel: every block ends with 832 atomics
   const int cap = 256 * (bpc > 2 ? 2 : bpc);
   const int grid = ceil_div(a.B, ceil_div(a.B, cap));
-  launch("conv1_pool_bwd", conv1_pool_bwd_kernel, dim3(grid), dim3(256), 0, stream, a);
+  launch("conv1_pool_bwd", conv1_pool_bwd_kernel, dim3(grid, a.B < 512 ? 2 : 1), dim3(256), 0, stream, a);
 }
 
 }  // namespace dtf

@@ -641,7 +641,7 @@ def test_flat_ops_and_elementwise():
     assert abs(nv.zero_fraction(torch.relu(a)) - float((torch.relu(a) == 0).float().mean())) < 1e-6
 
 
-@pytest.mark.parametrize("b", [1, 3, 70])
+@pytest.mark.parametrize("b", [1, 3, 70, 260, 520])
 def test_conv1_pool_fused_forward_and_backward(b):
     """Fused first LeNet layer: pooled maximum / winner against conv + bias + ReLU + max-pool, and
     filter / bias gradients against autograd of the unfused chain."""
