@@ -20,6 +20,15 @@
 //                  are persistent grids sized to two workgroups per CU with up to 243 vector
 //                  registers per lane, and a resident workgroup on a CU keeps one of the two from
 //                  being placed until the grid's tail (measured: +20 % on every convolution).
+// Consistency of a pull: it takes no lock. The version words are read first (a kernel of their
+// own), then the shards are copied while the owners' sweeps may be writing them, so one pull can
+// hold parameters of several versions of a shard - never older than the recorded version, possibly
+// newer, and possibly a shard that is part-way through an update. That is the consistency of the
+// reference's workers reading variables from the parameter server while it applies other workers'
+// gradients, and what the staleness bound is defined against (the recorded version is a lower bound).
+// The optimizer slots of a shard live in peer-mapped buffers next to the authoritative parameters,
+// so the chief can copy the whole optimizer state of every owner into its arena for a checkpoint
+// without stopping anybody (DeviceAsyncShards.gather_state).
 // Nobody waits for another replica's compute; a push waits (bounded) only for its own previous push
 // to the same owner to be consumed, and is dropped if that does not happen in time.
 #pragma once
@@ -56,7 +65,7 @@ struct AsyncArgs {
   float* inbox[kAsyncMaxPeers];              // owner o's inboxes: [world][shard_floats], this pointer = o's base
   float* params;                             // local arena (padded): world * shard_floats floats
   const float* grads;                        // local gradient, same layout
-  float* m;                                  // local optimizer slots, same layout (only the own range is used)
+  float* m;                                  // optimizer slots of the OWN shard: shard_floats floats each
   float* v;
   unsigned long long* status;                // host-visible mirror (nullable): [0..7] pulled versions, [8..] stats
   long long shard_floats;                    // floats per shard, multiple of 4

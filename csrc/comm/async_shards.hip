@@ -16,18 +16,24 @@ constexpr u64 kExit = 1000, kNone = 1001;
 __device__ __forceinline__ void bump(u64* own, int which, u64 by = 1) { st(W(own, AW_STATS + which), ld(W(own, AW_STATS + which)) + by); }
 
 // ---- pull ---------------------------------------------------------------------------------------------
-// The version word is read BEFORE the data: the gradient computed on these parameters is tagged
-// with a version that is at most as new as what was read, so staleness is never under-estimated.
-__global__ __launch_bounds__(256) void async_pull_kernel(AsyncArgs a) {
+// The version words are read by a one-thread-per-owner kernel launched BEFORE the copy kernel:
+// kernels of one stream run in order, so every data load of every block of the copy comes after
+// the version reads, and the gradient computed on these parameters is tagged with a version that
+// is at most as new as any value that was copied: staleness is never under-estimated. (Read inside
+// the copy kernel by block 0 only, a block scheduled ahead of block 0 could copy older values than
+// the recorded version.) A pull does not exclude the owner's service sweep: see async_shards.h.
+__global__ void async_pull_begin_kernel(AsyncArgs a) {
+  if (blockIdx.x != 0 || (int)threadIdx.x >= a.world) return;
   u64* own = a.ctl[a.rank];
+  const u64 v = ld_acq(W(a.ctl[threadIdx.x], AW_VERSION));
+  st(W(own, AW_PULLED + threadIdx.x), v);
+  if (a.status) st(a.status + threadIdx.x, v);
+}
+
+__global__ __launch_bounds__(256) void async_pull_kernel(AsyncArgs a) {
   const long long n4 = a.shard_floats >> 2;
   const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long gstride = (long long)gridDim.x * blockDim.x;
-  if (blockIdx.x == 0 && (int)threadIdx.x < a.world) {
-    const u64 v = ld_acq(W(a.ctl[threadIdx.x], AW_VERSION));
-    st(W(own, AW_PULLED + threadIdx.x), v);
-    if (a.status) st(a.status + threadIdx.x, v);
-  }
   acquire_fence();
   floatx4* dst = reinterpret_cast<floatx4*>(a.params);
   for (int k = 0; k < a.world; ++k) {
@@ -133,12 +139,12 @@ __global__ __launch_bounds__(256) void async_service_kernel(AsyncArgs a) {
     acquire_fence();
     const floatx4* g4 = reinterpret_cast<const floatx4*>(a.inbox[a.rank]) + (long long)s * n4;
     floatx4* p4 = reinterpret_cast<floatx4*>(a.shard[a.rank]);
-    floatx4* m4 = reinterpret_cast<floatx4*>(a.m) + (long long)a.rank * n4;
+    floatx4* m4 = reinterpret_cast<floatx4*>(a.m);   // the own shard's slots (peer-mapped, read by the chief at a save)
     const long long t = version + 1;
     const double lr = (double)a.lr0 * pow((double)a.decay, (double)(version / (a.decay_steps > 0 ? a.decay_steps : 1)));
     if (a.opt == 0) {
       const float lr_t = (float)(lr * sqrt(1.0 - pow((double)a.beta2, (double)t)) / (1.0 - pow((double)a.beta1, (double)t)));
-      floatx4* v4 = reinterpret_cast<floatx4*>(a.v) + (long long)a.rank * n4;
+      floatx4* v4 = reinterpret_cast<floatx4*>(a.v);
       for (long long i = gtid; i < n4; i += gstride) {
         floatx4 p = p4[i], m = m4[i], v = v4[i];
         adam_update4(p, m, v, g4[i], 1.f, lr_t, a.beta1, a.beta2, a.eps);
@@ -184,6 +190,7 @@ void validate(const AsyncArgs& a, int blocks) {
 void async_pull(const AsyncArgs& a, int blocks, hipStream_t stream) {
   validate(a, blocks);
   if (!a.params) throw std::runtime_error("async shards: null parameter arena");
+  launch("async_pull_begin", async_pull_begin_kernel, dim3(1), dim3(64), 0, stream, a);
   launch("async_pull", async_pull_kernel, dim3(blocks), dim3(256), 0, stream, a);
 }
 
