@@ -320,6 +320,9 @@ PYBIND11_MODULE(_hip, m) {
     m.def("ulog_poke", [](uint64_t ctl, int word, unsigned long long value) {
       ulog_poke(reinterpret_cast<unsigned long long*>(ctl), word, value);
     });
+    m.def("ulog_poke_async", [](uint64_t ctl, int word, unsigned long long value, long long delay_ticks, uint64_t stream) {
+      ulog_poke_async(reinterpret_cast<unsigned long long*>(ctl), word, value, delay_ticks, as_stream(stream));
+    });
     // ---- asynchronous parameter shards
     auto afill = [](const py::dict& d) {
       AsyncArgs a{};

@@ -95,6 +95,8 @@ PYBIND11_MODULE(_host, m) {
       .def("advance_global_step", &Board::advance_global_step)
       .def("request_stop", &Board::request_stop)
       .def("should_stop", &Board::should_stop)
+      .def("report_failure", &Board::report_failure)
+      .def("failed_rank", &Board::failed_rank)
       .def("open_step", &Board::open_step)
       .def("arrive", &Board::arrive, py::arg("step"), py::arg("rank"), py::arg("quorum") = 0)
       .def("arrive_aborted", &Board::arrive_aborted)
@@ -128,6 +130,7 @@ PYBIND11_MODULE(_host, m) {
       .def_property_readonly_static("DEPARTED", [](py::object) { return Board::kDeparted; })
       .def("shard_version", &Board::shard_version)
       .def("bump_shard_version", &Board::bump_shard_version)
+      .def("set_shard_version", &Board::set_shard_version)
       .def("ring_doorbell", &Board::ring_doorbell)
       .def("poll_doorbell", &Board::poll_doorbell)
       .def("clear_doorbell", &Board::clear_doorbell)

@@ -112,5 +112,9 @@ void ulog_mark_dead(unsigned long long* ctl, unsigned mask, hipStream_t stream);
 void ulog_peek(const unsigned long long* ctl, int first, int count, unsigned long long* out);
 // Overwrites one control word from the host (synchronous; tests and fault injection only).
 void ulog_poke(unsigned long long* ctl, int word, unsigned long long value);
+// The same store from a one-thread kernel on `stream`, `delay_ticks` (100 MHz) after the kernel
+// started: lands while other streams' kernels run (tests raise the abort word in the middle of a
+// step this way).
+void ulog_poke_async(unsigned long long* ctl, int word, unsigned long long value, long long delay_ticks, hipStream_t stream);
 
 }  // namespace dtf

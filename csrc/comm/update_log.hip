@@ -107,16 +107,49 @@ __device__ __forceinline__ void raise_error(u64* own, int code) {
   if (ld(W(own, UW_ERROR)) == 0) st(W(own, UW_ERROR), (u64)code);
 }
 
-// Publishes the record of update u on every replica's block and opens u + 1. Called by exactly one
-// thread in the whole job: the one whose compare-exchange set the frozen bit.
+// Publishes the record of update u on every replica's block and opens u + 1. Called by the thread
+// whose compare-exchange set the frozen bit - and, should that replica die between the two, by the
+// contributor that stands in for it (republish_if_closer_died): both write the same record, and the
+// next update is opened by a compare-exchange from the frozen word, so it is opened exactly once
+// (a plain store by a closer that was only slow could wipe out arrivals for u + 1).
 __device__ void publish_closed(const UlogArgs& a, long long u, int count, unsigned mask, unsigned owners, float scale,
                                bool closer_reduces) {
   const int slot = (int)(u % kUlogRing);
   const u64 aux = ((u64)(closer_reduces ? 1 : 0) << 63) | ((u64)(owners & 0xffff) << 32) | (u64)__float_as_uint(scale);
   const u64 tag = ((u64)(u + 1) << 32) | ((u64)(count & 0xffff) << 16) | (u64)(mask & 0xffff);
-  for (int p = 0; p < a.world; ++p) st(W(a.ctl[p], UW_HIST_AUX + slot), aux);
-  for (int p = 0; p < a.world; ++p) st_rel(W(a.ctl[p], UW_HIST_TAG + slot), tag);
-  st_rel(W(a.ctl[0], UW_OPEN), make_open(u + 1, 0, 0, false));
+  const unsigned dead = (unsigned)ld(W(a.ctl[a.rank], UW_DEAD));   // a dead replica's block may be gone
+  for (int p = 0; p < a.world; ++p)
+    if (!((dead >> p) & 1u)) st(W(a.ctl[p], UW_HIST_AUX + slot), aux);
+  for (int p = 0; p < a.world; ++p)
+    if (!((dead >> p) & 1u)) st_rel(W(a.ctl[p], UW_HIST_TAG + slot), tag);
+  u64 frozen_word = make_open(u, count, mask, true);
+  cas(W(a.ctl[0], UW_OPEN), frozen_word, make_open(u + 1, 0, 0, false));
+}
+
+// The replica whose arrival completed the quorum of update u froze the open word and died before it
+// published the closed record: the word still says who contributed and how many gradients there
+// are, which is all the record holds. Of the contributors that are waiting for that record, the
+// lowest-ranked live one publishes it in the closer's place. Only contributors do: they carry the
+// scale of the update in their launch arguments. Conditions: the word is frozen at u, a contributor
+// of u is marked dead (the watchdog takes seconds to say so; a live closer needs microseconds), the
+// coordinator is alive (its block holds the word), and the state has lasted `grace` ticks.
+__device__ bool republish_if_closer_died(const UlogArgs& a, u64* own, long long u, long long& frozen_since) {
+  if (a.mode != ULOG_CONTRIBUTE) return false;
+  const unsigned dead = (unsigned)ld(W(own, UW_DEAD));
+  if (!dead || (dead & 1u)) return false;
+  const u64 w = ld_acq(W(a.ctl[0], UW_OPEN));
+  if (!(w & kFrozen) || open_u(w) != u) {
+    frozen_since = 0;
+    return false;
+  }
+  const unsigned mask = open_mask(w), live = mask & ~dead;
+  if (!(mask & dead) || !live || (live & (0u - live)) != (1u << a.rank)) return false;
+  const long long now = wall_clock64();
+  if (!frozen_since) frozen_since = now;
+  if (now - frozen_since < 100000) return false;   // 1 ms at 100 MHz
+  const int count = open_count(w);
+  publish_closed(a, u, count, mask, mask, a.scale > 0.f ? a.scale : 1.f / (float)count, false);
+  return true;
 }
 
 __device__ void raise_abort_everywhere(const UlogArgs& a, long long value) {
@@ -240,6 +273,7 @@ __device__ u64 next_action(const UlogArgs& a, u64* own, long long u, long long w
   if (ld(W(own, UW_ERROR)) != 0) return kActError;
   const bool patient = a.mode == ULOG_CONTRIBUTE || a.mode == ULOG_SKIP;
   const long long t0 = wall_clock64();
+  long long frozen_since = 0;
   for (;;) {
     Rec r;
     const int c = read_hist(own, u, r);
@@ -253,6 +287,7 @@ __device__ u64 next_action(const UlogArgs& a, u64* own, long long u, long long w
       return kActError;
     }
     if (u != wait_u) return kActDone;
+    if (republish_if_closer_died(a, own, u, frozen_since)) continue;
     if (wall_clock64() - t0 > a.timeout_ticks) {
       raise_error(own, UE_CLOSE);
       return kActError;
@@ -542,6 +577,13 @@ __global__ void ulog_mark_dead_kernel(u64* ctl, unsigned mask) {
   __hip_atomic_fetch_or(W(ctl, UW_DEAD), (u64)mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+__global__ void ulog_poke_kernel(u64* ctl, int word, u64 value, long long delay_ticks) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < delay_ticks) nap();
+  st_rel(W(ctl, word), value);
+}
+
 void validate(const UlogArgs& a, int blocks, bool needs_optimizer) {
   if (a.world < 1 || a.world > kUlogMaxPeers || a.rank < 0 || a.rank >= a.world) throw std::runtime_error("update log: bad rank/world");
   if (a.n <= 0 || (a.n & 3)) throw std::runtime_error("update log: n must be a positive multiple of 4");
@@ -591,6 +633,13 @@ void ulog_peek(const unsigned long long* ctl, int first, int count, unsigned lon
 void ulog_poke(unsigned long long* ctl, int word, unsigned long long value) {
   if (!ctl || word < 0 || word >= UW_COUNT) throw std::runtime_error("update log: bad poke word");
   DTF_HIP_CHECK(hipMemcpy(ctl + (size_t)word * kUlogWordStride, &value, sizeof(value), hipMemcpyHostToDevice));
+}
+
+void ulog_poke_async(unsigned long long* ctl, int word, unsigned long long value, long long delay_ticks, hipStream_t stream) {
+  if (!ctl || word < 0 || word >= UW_COUNT) throw std::runtime_error("update log: bad poke word");
+  if (delay_ticks < 0 || delay_ticks > 100000000) throw std::runtime_error("update log: poke delay must be within a second");
+  hipLaunchKernelGGL(ulog_poke_kernel, dim3(1), dim3(64), 0, stream, ctl, word, value, delay_ticks);
+  DTF_HIP_CHECK(hipGetLastError());
 }
 
 }  // namespace dtf

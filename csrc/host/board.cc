@@ -135,6 +135,11 @@ void Board::set_global_step(int64_t s) { lay_->global_step.store(s, std::memory_
 int64_t Board::advance_global_step() { return lay_->global_step.fetch_add(1, std::memory_order_acq_rel) + 1; }
 void Board::request_stop() { lay_->should_stop.store(1, std::memory_order_release); }
 bool Board::should_stop() const { return lay_->should_stop.load(std::memory_order_acquire) != 0; }
+void Board::report_failure(int rank) { lay_->should_stop.store(2 + rank, std::memory_order_release); }
+int Board::failed_rank() const {
+  const int32_t v = lay_->should_stop.load(std::memory_order_acquire);
+  return v >= 2 ? v - 2 : -1;
+}
 
 // ---- per-step protocol ---------------------------------------------------------------------------
 BoardStepSlot& Board::slot(int64_t step) const {
@@ -238,6 +243,7 @@ void Board::depart(int rank) { lay_->heartbeat_ns[rank].store(kDeparted, std::me
 
 // ---- async shards -------------------------------------------------------------------------------------
 int64_t Board::shard_version(int owner) const { return lay_->shard_version[owner].load(std::memory_order_acquire); }
+void Board::set_shard_version(int owner, int64_t version) { lay_->shard_version[owner].store(version, std::memory_order_release); }
 int64_t Board::bump_shard_version(int owner) {
   return lay_->shard_version[owner].fetch_add(1, std::memory_order_acq_rel) + 1;
 }

@@ -109,6 +109,10 @@ class Board {
   int64_t advance_global_step();
   void request_stop();
   bool should_stop() const;
+  // A worker whose helper thread (interval timer, shard service) failed stops the job and leaves its
+  // rank for the others' watchdogs to name; -1 = nobody did.
+  void report_failure(int rank);
+  int failed_rank() const;
 
   // ---- per-step arrival protocol
   // Opens the step window if nobody did yet and returns its start time.
@@ -146,6 +150,7 @@ class Board {
   // ---- async parameter shards
   int64_t shard_version(int owner) const;
   int64_t bump_shard_version(int owner);
+  void set_shard_version(int owner, int64_t version);              // a resumed run continues the restored step count
   bool ring_doorbell(int owner, int sender, int64_t local_step);   // false if the previous push is still pending
   int64_t poll_doorbell(int owner, int sender) const;              // -1 if empty, else local_step
   void clear_doorbell(int owner, int sender);

@@ -25,6 +25,9 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 namespace dtf {
 
 constexpr int kStatSlots = 8;
+// Dynamic LDS a kernel may ask for: the CU's 160 KB less a line for the few statically allocated
+// words (the abort guard's verdict).
+constexpr size_t kLdsBudget = 160 * 1024 - 128;
 
 // Total of statistic `idx` (0..2C-1) over the slots.
 __device__ __forceinline__ double stat_total(const double* sums, int idx, int C) {
@@ -119,14 +122,24 @@ __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; 
 
 namespace dtf {
 // True when the replica's current update is already complete (see AbortRef). Both words live in
-// memory that other GPUs write, so they are read past the caches; the verdict is uniform over the
-// grid in practice and any mix of early and late readers is harmless: a kernel either runs or
-// leaves its outputs at the zeros the step prologue wrote.
+// memory that other GPUs write, so they are read past the caches. The verdict is taken ONCE per
+// workgroup - thread 0 reads the two words, everybody branches on the copy in LDS - so a workgroup
+// runs as a whole or not at all: were every thread to read for itself, a stop word rising while a
+// workgroup starts could make some of its waves return and the others run on past barriers that no
+// longer wait for the waves that left, over LDS they never filled. Between workgroups any mix of
+// early and late readers is harmless: a tile is either computed or left at the zeros the step
+// prologue wrote. Replicas recorded without an abort reference (null pointers, a kernel argument)
+// skip the barrier as well.
 __device__ __forceinline__ bool dtf_aborted(const AbortRef& r) {
   if (!r.stop) return false;
-  const unsigned long long s = __hip_atomic_load(r.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const unsigned long long v = __hip_atomic_load(r.version, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  return s > v;
+  __shared__ int s_aborted;
+  if ((threadIdx.x | threadIdx.y | threadIdx.z) == 0) {
+    const unsigned long long s = __hip_atomic_load(r.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long v = __hip_atomic_load(r.version, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    s_aborted = s > v;
+  }
+  __syncthreads();
+  return s_aborted != 0;
 }
 }  // namespace dtf
 #define DTF_ABORT_GUARD(args) do { if (dtf::dtf_aborted((args).abort)) return; } while (0)

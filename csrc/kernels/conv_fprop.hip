@@ -288,7 +288,7 @@ size_t launch_fprop(const ConvFpropArgs& a, hipStream_t stream) {
   const int LH = (a.TH - 1) * S + KS, LW = (a.TW - 1) * S + KS;
   const size_t floats = (size_t)((LH * LW * CPP + 3) & ~3) + (size_t)KG * NT * 256 + 2 * CP + 2 * NT * 16;
   const size_t shmem = floats * sizeof(float);
-  if (shmem > 160 * 1024) throw std::runtime_error("conv_fprop: tile does not fit LDS");
+  if (shmem > kLdsBudget) throw std::runtime_error("conv_fprop: tile does not fit LDS");
   const int zsplit = a.nt_total / NT;
   const int total_tiles = a.tiles_y * a.tiles_x * a.B;
   const int t8 = (total_tiles + 7) / 8 * 8;
@@ -339,7 +339,7 @@ int choose_nt(const ConvFpropArgs& a, int ks, int cp, int s) {
   }
   for (int nt : cands) {
     if (a.nt_total % nt) continue;
-    if (lds_bytes(ks, s, cp, nt, a.TH, a.TW) <= 160 * 1024) return nt;
+    if (lds_bytes(ks, s, cp, nt, a.TH, a.TW) <= kLdsBudget) return nt;
   }
   throw std::runtime_error("conv_fprop: no tiling fits LDS");
 }
@@ -399,7 +399,7 @@ size_t conv_fprop(const ConvFpropArgs& a_in, int ks, hipStream_t stream) {
   if ((a.Cin & 3) != 0 && a.Cin > 4) throw std::runtime_error("conv_fprop: Cin must be <=4 or a multiple of 4");
   if (a.Cout & 3) throw std::runtime_error("conv_fprop: Cout must be a multiple of 4");
   // Shrink the tile until the smallest configuration fits.
-  while (lds_bytes(ks, s, cp, 1, a.TH, a.TW) > 160 * 1024 && a.TH > 1) {
+  while (lds_bytes(ks, s, cp, 1, a.TH, a.TW) > kLdsBudget && a.TH > 1) {
     a.TH = (a.TH + 1) / 2;
     a.tiles_y = ceil_div(a.Ho, a.TH);
   }

@@ -351,7 +351,7 @@ size_t launch_persist(const ConvFpropArgs& a, hipStream_t stream) {
   // Co-resident blocks per CU: LDS-limited, and capped by the register budget the kernel was
   // compiled for (__launch_bounds__: 3 waves per SIMD for the shallow single-N-tile kernels, else 2).
   const int reg_bpc = (CP <= 16 && NT == 1) ? 3 : 2;
-  int bpc = (int)((160 * 1024) / shmem);
+  int bpc = (int)((kLdsBudget) / shmem);
   if (bpc > reg_bpc) bpc = reg_bpc;
   if (bpc < 1) bpc = 1;
   int gpz_max = (256 * bpc) / zsplit;
@@ -396,7 +396,7 @@ size_t conv_fprop_persist(const ConvFpropArgs& a_in, int ks, hipStream_t stream)
   int nt = a.nt_total;
   while (nt > 1 && (lds_bytes_p(3, s, cp, nt, a.TH, a.TW) > 80 * 1024 || nt == 3)) nt >>= 1;
   if (a.nt_total % nt) return 0;
-  if (lds_bytes_p(3, s, cp, nt, a.TH, a.TW) > 160 * 1024) return 0;
+  if (lds_bytes_p(3, s, cp, nt, a.TH, a.TW) > kLdsBudget) return 0;
   const bool mtw2 = (n_mt >= 8) && nt <= 2;
 
 #define DTF_PCASE(S_, CP_, NT_, MTW_, NPF_)                                                         \

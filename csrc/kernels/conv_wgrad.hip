@@ -249,7 +249,7 @@ size_t launch_wgrad(const ConvWgradArgs& a, hipStream_t stream) {
   if (tile_floats < one_tap) tile_floats = one_tap;
   const size_t floats = tile_floats + 2 * CP;
   const size_t shmem = floats * sizeof(float);
-  if (shmem > 160 * 1024) throw std::runtime_error("conv_wgrad: tile does not fit LDS");
+  if (shmem > kLdsBudget) throw std::runtime_error("conv_wgrad: tile does not fit LDS");
   const int total_tiles = a.tiles_y * a.tiles_x * a.B;
   const int gx = ceil_div(total_tiles, a.tiles_per_block);
   const int gy = ceil_div(ceil_div(a.Cout, 16), CO_T);

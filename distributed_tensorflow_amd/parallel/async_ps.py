@@ -66,7 +66,7 @@ class AsyncParameterShards:
         return object.__new__(cls)
 
     def __init__(self, replica, comm: Communicator, board, staleness_bound: int, name: str, lr_fn,
-                 push_timeout_s: float = 30.0):
+                 push_timeout_s: float = 30.0, start_version: int = 0):
         if board is None:
             raise ValueError("asynchronous shards need the shared-memory control board")
         self.replica, self.comm, self.board = replica, comm, board
@@ -78,58 +78,59 @@ class AsyncParameterShards:
         self.push_timeout_s = push_timeout_s
         self.stats = AsyncStats()
         self.staleness_hist: List[int] = [0] * 16
-        self.on_gpu = self.arena.params.is_cuda
+        self.on_gpu = False
+        self.start_version = max(0, int(start_version))
         self._name = name.strip("/").replace("/", "_")
-        self._pulled_version: List[int] = [0] * self.world
+        self._pulled_version: List[int] = [self.start_version] * self.world
         self._files: List[str] = []
+        self._slot_names = sorted(self.arena.slots)          # "m", "v" (Adam) or "m" (momentum SGD)
+        # a resumed run continues the restored step count: learning-rate staircase and Adam's bias
+        # correction are functions of the shard's version
+        self.board.set_shard_version(self.rank, self.start_version)
         self._map_regions()
 
     # ------------------------------------------------------------------------------------------
     def _map_regions(self) -> None:
+        """The owner creates its regions - the authoritative parameters of its shard, its optimizer
+        slots and one inbox per sender - from its (restored or freshly initialised) arena, and
+        everybody maps all of them. The slots are mapped by everybody so that the chief can copy
+        the whole optimizer state into its arena for a checkpoint (`gather_state`)."""
         lo, hi = self.bounds[self.rank]
         n_own = hi - lo
-        if self.on_gpu:
-            self._map_cuda_ipc(n_own)
-        else:
-            # owner creates its regions, everybody maps all of them
-            for s in range(self.world):
-                self._files.append(f"{self._name}_inbox_{self.rank}_{s}")
-                _shm_tensor(self._files[-1], n_own, True)
-            self._files.append(f"{self._name}_shard_{self.rank}")
-            own = _shm_tensor(self._files[-1], n_own, True)
-            own.copy_(self.arena.full("params")[lo:hi])
-            self.comm.barrier()
-            self.shards = []
-            self.inboxes: List[List[torch.Tensor]] = []
-            for o in range(self.world):
-                n_o = self.bounds[o][1] - self.bounds[o][0]
-                self.shards.append(_shm_tensor(f"{self._name}_shard_{o}", n_o, False))
-                self.inboxes.append([_shm_tensor(f"{self._name}_inbox_{o}_{s}", n_o, False) for s in range(self.world)])
-            self.comm.barrier()
-
-    def _map_cuda_ipc(self, n_own: int) -> None:
-        from torch.multiprocessing.reductions import reduce_tensor
-
-        dev = self.arena.params.device
-        own_shard = torch.empty(max(1, n_own), device=dev, dtype=torch.float32)
-        lo, hi = self.bounds[self.rank]
-        own_shard[:n_own].copy_(self.arena.full("params")[lo:hi])
-        own_inbox = [torch.zeros(max(1, n_own), device=dev, dtype=torch.float32) for _ in range(self.world)]
-        torch.cuda.synchronize()
-        self._own_keepalive = (own_shard, own_inbox)
-        handles = (reduce_tensor(own_shard), [reduce_tensor(t) for t in own_inbox])
-        all_handles = self.comm.all_gather_object(handles)
-        self.shards, self.inboxes = [], []
-        for o, (h_shard, h_inbox) in enumerate(all_handles):
-            if o == self.rank:
-                self.shards.append(own_shard)
-                self.inboxes.append(own_inbox)
-                continue
-            fn, args = h_shard
-            # rebuild on THIS process's device (peer mapping of the owner's memory)
-            self.shards.append(fn(*args))
-            self.inboxes.append([f(*a) for (f, a) in h_inbox])
+        for s in range(self.world):
+            self._files.append(f"{self._name}_inbox_{self.rank}_{s}")
+            _shm_tensor(self._files[-1], n_own, True)
+        self._files.append(f"{self._name}_shard_{self.rank}")
+        own = _shm_tensor(self._files[-1], n_own, True)
+        own.copy_(self.arena.full("params")[lo:hi])
+        for k in self._slot_names:
+            self._files.append(f"{self._name}_slot_{k}_{self.rank}")
+            _shm_tensor(self._files[-1], n_own, True).copy_(self.arena.full("slot:" + k)[lo:hi])
         self.comm.barrier()
+        self.shards = []
+        self.inboxes: List[List[torch.Tensor]] = []
+        self.slot_regions: List[dict] = []
+        for o in range(self.world):
+            n_o = self.bounds[o][1] - self.bounds[o][0]
+            self.shards.append(_shm_tensor(f"{self._name}_shard_{o}", n_o, False))
+            self.inboxes.append([_shm_tensor(f"{self._name}_inbox_{o}_{s}", n_o, False) for s in range(self.world)])
+            self.slot_regions.append({k: _shm_tensor(f"{self._name}_slot_{k}_{o}", n_o, False) for k in self._slot_names})
+        self.comm.barrier()
+
+    # ------------------------------------------------------------------------------------------
+    def gather_state(self) -> None:
+        """Copies every owner's authoritative parameters and optimizer slots into the LOCAL arena
+        (one-sided reads of the mapped regions; nobody is stopped, so the cut has the consistency
+        of a pull: each shard at some version at or after the one its owner last published).
+        The chief calls it before a checkpoint so that the saved state holds all variables, the
+        optimizer's included (reference: DistributedLeNet/src/distributed_train.py:212,234-242,370-373)."""
+        a = self.arena
+        for o, (lo, hi) in enumerate(self.bounds):
+            if hi <= lo:
+                continue
+            a.full("params")[lo:hi].copy_(self.shards[o][: hi - lo])
+            for k in self._slot_names:
+                a.full("slot:" + k)[lo:hi].copy_(self.slot_regions[o][k][: hi - lo])
 
     # ------------------------------------------------------------------------------------------
     def pull(self) -> None:
@@ -191,28 +192,14 @@ class AsyncParameterShards:
         return applied
 
     def _apply(self, grad: torch.Tensor, version: int) -> None:
-        a = self.arena
         lo, hi = self.bounds[self.rank]
         lr = self.lr_fn(version) if callable(self.lr_fn) else float(self.lr_fn)
         shard = self.shards[self.rank][: hi - lo]
-        opt = self.replica.optimizer
-        if self.on_gpu:
-            from ..ops import native as nv
-
-            with self.replica.stream_ctx():
-                hyper = torch.tensor(
-                    [ref.adam_lr_t(lr, version + 1) if opt == "adam" else lr, 0.9, 0.999, 1e-8, 1.0,
-                     self.replica.momentum, self.replica.weight_decay, 0.0], dtype=torch.float32).to(grad.device)
-                if opt == "adam":
-                    nv.fused_adam(shard, grad, a.full("slot:m")[lo:hi], a.full("slot:v")[lo:hi], hyper)
-                else:
-                    nv.fused_momentum_sgd(shard, grad, a.full("slot:m")[lo:hi], hyper)
-            self.replica.synchronize()
+        slots = self.slot_regions[self.rank]
+        if self.replica.optimizer == "adam":
+            ref.adam_update(shard, grad, slots["m"][: hi - lo], slots["v"][: hi - lo], ref.adam_lr_t(lr, version + 1))
         else:
-            if opt == "adam":
-                ref.adam_update(shard, grad, a.full("slot:m")[lo:hi], a.full("slot:v")[lo:hi], ref.adam_lr_t(lr, version + 1))
-            else:
-                ref.momentum_update(shard, grad, a.full("slot:m")[lo:hi], lr, self.replica.momentum, self.replica.weight_decay)
+            ref.momentum_update(shard, grad, slots["m"][: hi - lo], lr, self.replica.momentum, self.replica.weight_decay)
 
     # ------------------------------------------------------------------------------------------
     def step(self) -> Tuple[float, int]:
@@ -224,6 +211,12 @@ class AsyncParameterShards:
         self.push()
         self.service()
         return self.replica.loss_value(), self.board.global_step()
+
+    def own_state(self) -> dict:
+        """Copies of the own shard's authoritative parameters and optimizer slots (tests, debugging)."""
+        out = {"params": self.shards[self.rank].clone()}
+        out.update({k: t.clone() for k, t in self.slot_regions[self.rank].items()})
+        return out
 
     def versions(self) -> List[int]:
         """Updates applied to every shard so far."""
@@ -243,7 +236,7 @@ class AsyncParameterShards:
         self.board.barrier(timeout_s)
         self.service()
         self.board.barrier(timeout_s)
-        self.pull()
+        self.gather_state()      # final parameters AND every owner's optimizer slots, for the last checkpoint
 
     def close(self) -> None:
         for f in self._files:

@@ -196,6 +196,13 @@ class Watchdog(threading.Thread):
         while not self._stop_evt.wait(self.period_s):
             b.heartbeat(self.rank)
             if b.should_stop():
+                failed = b.failed_rank()
+                if failed >= 0 and failed != self.rank:
+                    # that worker's training thread raises the error itself; this one may be waiting
+                    # for it in a collective or a bounded device wait, so the process ends from here
+                    log.error("Worker %d: worker %d reported a failed helper thread and stopped the job (see its log); stopping",
+                              self.rank, failed)
+                    self._exit_now()
                 # a normal end of the run - or another worker's watchdog was faster: its verdict is on the board
                 mask = b.agg_dead()
                 gone = {r for r in range(self.world) if (mask >> r) & 1}

@@ -137,6 +137,13 @@ class StoreBoard:
     def should_stop(self) -> bool:
         return bool(self.store.check([self._k("stop")]))
 
+    def report_failure(self, rank: int) -> None:
+        self._set_int("failed", rank + 1)
+        self.request_stop()
+
+    def failed_rank(self) -> int:
+        return self._get_int("failed") - 1
+
     def set_local_step(self, rank: int, s: int) -> None:
         self._set_int(f"lstep/{rank}", s)
 
@@ -194,7 +201,7 @@ class StoreBoard:
     def _no_async(self, *_a):
         raise NotImplementedError("asynchronous parameter shards need workers that can map each other's memory (one node)")
 
-    shard_version = bump_shard_version = ring_doorbell = poll_doorbell = clear_doorbell = _no_async
+    shard_version = bump_shard_version = set_shard_version = ring_doorbell = poll_doorbell = clear_doorbell = _no_async
 
     # -- update log (semantics of csrc/host/board.cc, word for word) --------------------------------
     def agg_reset(self, u0: int) -> None:

@@ -246,6 +246,7 @@ class Interval(_LogStrategy):
         self.max_staleness = max_staleness
         self._timer: Optional[threading.Thread] = None
         self._timer_stop = threading.Event()
+        self._timer_error: Optional[BaseException] = None   # what ended the timer thread
         self.windows_closed = 0
         self._lr: LrLike = 0.0
 
@@ -255,20 +256,38 @@ class Interval(_LogStrategy):
         if self._timer is not None or not self.comm.is_chief:
             return
         log = self._get_log(replica)
+        import os
+
+        fault_after = int(os.environ.get("DTF_FAULT_INTERVAL_TIMER", "0"))   # tests: the timer fails after this many windows
 
         def tick() -> None:
             nxt = time.time() + self.interval_s
             while not self._timer_stop.wait(max(0.0, nxt - time.time())):
                 nxt += self.interval_s
                 try:
+                    if fault_after and self.windows_closed >= fault_after:
+                        raise RuntimeError("injected fault (DTF_FAULT_INTERVAL_TIMER)")
                     if log.close_window() >= 0:
                         self.windows_closed += 1
-                except Exception:   # noqa: BLE001 - the training thread reports the failure
-                    self._timer_error = True
+                except Exception as e:   # noqa: BLE001 - kept for the training thread (check_timer)
+                    self._timer_error = e
                     return
 
         self._timer = threading.Thread(target=tick, name="interval-updates", daemon=True)
         self._timer.start()
+
+    def check_timer(self) -> None:
+        """Every step of the chief's training thread. Without the timer no window ever closes again
+        while the workers - which never wait in this mode - go on pushing: the job is stopped and
+        the error raised by name instead of a silent stall of the global step."""
+        err = self._timer_error
+        if err is None and self._timer is not None and not self._timer.is_alive() and not self._timer_stop.is_set():
+            err = RuntimeError("thread ended without an error")
+        if err is not None:
+            self._timer_error = None
+            if self.board is not None:
+                self.board.report_failure(self.rank)
+            raise RuntimeError(f"interval updates (worker {self.rank}): the timer thread failed: {err!r}") from err
 
     def stop_interval_updates(self) -> None:
         if self._timer is not None:
@@ -285,6 +304,7 @@ class Interval(_LogStrategy):
         t0 = time.time()
         log = self._get_log(replica)
         self.start_interval_updates(replica)
+        self.check_timer()
         with replica.span("update log: apply closed windows"):
             log.catch_up(lr, reduce_own=False)  # start from the newest parameters, like a worker reading the parameter server
         with replica.span("forward+backward"):
@@ -295,6 +315,7 @@ class Interval(_LogStrategy):
         if self._plain():
             return self._plain_apply(pending, lr)
         log = self._get_log(pending.replica)
+        self.check_timer()
         with pending.replica.span("update log: push into the open window"):
             res = log.contribute_open(lr, self.max_staleness)
         return self._result(res, pending.done, log.contributors_hint(), pending.compute_s)

@@ -248,6 +248,9 @@ def train(flags, model: str) -> Dict:
         shards = AsyncParameterShards(
             replica, comm, board, flags.staleness_bound if flags.staleness_bound >= 0 else 2 * world, name,
             lr_mod.StaircaseSchedule(flags.initial_learning_rate, decay_steps, flags.learning_rate_decay_factor),
+            # every owner's shard continues at the restored step: the learning-rate staircase and
+            # Adam's bias correction are functions of the shard's version
+            start_version=global_step,
         )
         board.set_global_step(global_step) if is_chief else None
         strategy = None
@@ -330,8 +333,13 @@ def train(flags, model: str) -> Dict:
         timeline.reset(getattr(replica, "stream", None))
         log.info("RUNNING SESSION... %f" % time.time())
         if async_mode:
-            with timeline.span("async_step"):
-                loss_value, step = shards.step()
+            try:
+                with timeline.span("async_step"):
+                    loss_value, step = shards.step()
+            except RuntimeError as e:
+                if board.failed_rank() == rank:
+                    log.error("Worker %d: %s", rank, e)
+                raise
             if board.global_step() > flags.max_steps:
                 board.request_stop()
         else:
@@ -342,6 +350,9 @@ def train(flags, model: str) -> Dict:
                 # A collective that lost its peer fails at once on some transports (TCP resets) and
                 # hangs on others; either way the liveness watchdog is the one that says WHO died and
                 # ends the process. Give it its time before passing the transport's error on.
+                if board is not None and board.failed_rank() == rank:
+                    log.error("Worker %d: %s", rank, e)     # this worker's own helper thread: nothing to wait for
+                    raise
                 if watchdog is not None:
                     log.error("Worker %d: step failed (%s); waiting for the liveness verdict", rank, str(e).splitlines()[0][:200])
                     watchdog.join(timeout=2.0 * watchdog.silence_s + 5.0)
@@ -415,6 +426,10 @@ def train(flags, model: str) -> Dict:
                 strategy.gather_optimizer_state(replica)
                 sv.maybe_save(step, replica.updates_applied, force=True)
         else:
+            if async_mode and sv.save_due(step):
+                # the chief copies every owner's authoritative parameters and optimizer slots out of
+                # the mapped shards: the checkpoint holds all variables, not just the chief's range
+                shards.gather_state()
             sv.maybe_save(step, replica.updates_applied)
     lost = board is not None and board.agg_dead() != 0   # workers the watchdog gave up on: no collective can include them
 

@@ -304,6 +304,36 @@ def test_a_killed_worker_is_noticed_by_name(tmp_path, mode):
         assert steps[-1] >= 120
 
 
+def test_a_failed_interval_timer_stops_the_job_by_name(tmp_path):
+    """Interval mode: the chief's timer thread fails after four windows. Without a report the
+    workers - which never wait in this mode - would push forever while the global step stalls;
+    instead the chief raises the error by name at its next step and the other worker's watchdog ends
+    it within its polling period."""
+    from distributed_tensorflow_amd.launch import free_port
+
+    d = str(tmp_path)
+    os.environ["DTF_FAULT_INTERVAL_TIMER"] = "4"
+    try:
+        procs, logs = _start_ranks(2, ["--max_steps=100000", "--interval_method=true", "--interval_ms=30"], d, free_port())
+    finally:
+        del os.environ["DTF_FAULT_INTERVAL_TIMER"]
+    try:
+        rcs = [p.wait(timeout=120) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for f in logs:
+            f.close()
+    out = [open(os.path.join(d, f"rank{r}.log")).read() for r in range(2)]
+    assert rcs[0] != 0 and rcs[1] == 3, (rcs, out[0][-2000:], out[1][-2000:])
+    assert "the timer thread failed" in out[0] and "injected fault" in out[0]
+    assert "worker 0 reported a failed helper thread" in out[1]
+    # stopped at once: the chief's last window was the fourth, nobody trained on for long
+    steps = [int(m.group(2)) for m in (TRAIN_RE.match(l) for l in out[1].splitlines()) if m]
+    assert steps and steps[-1] <= 5
+
+
 def test_ranks_on_several_machines_coordinate_through_the_store(tmp_path):
     """LOCAL_WORLD_SIZE < WORLD_SIZE means the ranks sit on several machines: the control board and
     the update log's regions then live in the process group's key-value store. Full sync trains,

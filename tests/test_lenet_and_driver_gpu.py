@@ -195,6 +195,73 @@ def test_async_parameter_shards_in_hbm_over_ipc():
     assert out[0]["losses"][-1] < out[0]["losses"][0]
 
 
+def _gpu_async_ckpt_worker(rank, world, board_name, tmp):
+    import torch
+
+    from distributed_tensorflow_amd.checkpoint.saver import Saver
+    from distributed_tensorflow_amd.parallel import control_plane
+    from distributed_tensorflow_amd.parallel.async_ps import AsyncParameterShards
+    from distributed_tensorflow_amd.parallel.comm import Communicator
+    from distributed_tensorflow_amd.train.replica import HipReplica
+
+    os.environ["LOCAL_RANK"] = "0"
+    comm = Communicator.from_env(backend="gloo")
+    board = control_plane.open_board(board_name, world, rank)
+    g = torch.Generator().manual_seed(70 + rank)
+    images, labels = torch.randn(16, 32, 32, 3, generator=g), torch.randint(0, 10, (16,), generator=g)
+    rep = HipReplica("resnet", 16, num_residual_blocks=1)
+    rep.load_batch(images, labels)
+    control_plane.launch_manager(board, rank, world, 120)
+    shards = AsyncParameterShards(rep, comm, board, 8, board_name + "_ps", lambda v: 1e-3)
+    for _ in range(6):
+        shards.step()
+    rep.synchronize()
+    comm.barrier()
+    shards.service()                    # nothing left in any inbox
+    comm.barrier()
+    own = {k: t.cpu() for k, t in shards.own_state().items()}
+    versions = shards.versions()
+    n = shards.shard_floats
+    blank_outside = float(rep.arena.full("slot:m")[n:2 * n].abs().max()) if rank == 0 else 0.0
+    prefix = None
+    if rank == 0:
+        shards.gather_state()           # peer reads of rank 1's shard and slots
+        prefix = Saver(rep.arena, "adam").save(tmp, versions[0], versions[0])
+    prefix = comm.all_gather_object(prefix)[0]
+    shards.close()
+    # resume in fresh replicas
+    rep2 = HipReplica("resnet", 16, num_residual_blocks=1)
+    rep2.load_batch(images, labels)
+    step = Saver(rep2.arena, "adam").restore(prefix)
+    shards2 = AsyncParameterShards(rep2, comm, board, 8, board_name + "_ps2", lambda v: 1e-3, start_version=step)
+    back = {k: t.cpu() for k, t in shards2.own_state().items()}
+    err = {k: float((back[k] - own[k]).abs().max()) for k in own}
+    v0 = shards2.versions()
+    comm.barrier()                      # nobody pushes before everybody has looked
+    shards2.step()
+    shards2.drain(60)
+    v1 = shards2.versions()
+    kind = type(shards2).__name__
+    shards2.close()
+    comm.barrier()
+    comm.close()
+    return dict(err=err, nonzero=float(own["m"].abs().sum()), versions=versions, step=step, v0=v0, v1=v1,
+                blank_outside=blank_outside, kind=kind)
+
+
+def test_async_checkpoint_holds_every_owners_optimizer_state_and_resumes(tmp_path):
+    """Asynchronous run -> checkpoint written by the chief from the peer-mapped shards -> resume: every
+    owner's m / v / parameters equal the pre-save values and the shard versions continue (the Saver of
+    the reference stores all variables, Adam's slots included: DistributedLeNet/src/distributed_train.py:212,234-242)."""
+    out = run_workers(_gpu_async_ckpt_worker, 2, f"dtf_g_asck_{os.getpid()}", str(tmp_path), timeout=300)
+    assert all(o["kind"] == "DeviceAsyncShards" for o in out)
+    assert out[0]["blank_outside"] == 0.0       # the chief's own arena never held rank 1's slots
+    for o in out:
+        assert o["nonzero"] > 0 and set(o["err"]) == {"params", "m", "v"} and all(e == 0.0 for e in o["err"].values()), o
+        assert o["step"] == o["versions"][0] == 12
+        assert o["v0"] == [12, 12] and o["v1"] == [14, 14]
+
+
 @pytest.mark.parametrize("mode", ["backup", "backup_unsynced", "interval", "async", "soft_kill", "backup_host_fallback", "backup_store"])
 def test_driver_runs_the_straggler_policies_on_the_device_update_log(tmp_path, mode):
     """Entry script -> driver -> policy, two workers sharing GPU 0 (gloo carries the set-up exchange, the

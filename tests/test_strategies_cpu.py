@@ -306,6 +306,61 @@ def test_async_staleness_bound_drops_old_gradients():
     assert len({round(o["psum"], 3) for o in out}) == 1
 
 
+def _async_ckpt_worker(rank, world, board_name, tmp):
+    from distributed_tensorflow_amd.checkpoint.saver import Saver
+    from distributed_tensorflow_amd.parallel.async_ps import AsyncParameterShards
+    from distributed_tensorflow_amd.train.replica import TorchReplica
+
+    comm, board, rep, images, labels = _setup(rank, world, board_name)
+    shards = AsyncParameterShards(rep, comm, board, 8, board_name + "_ps", lambda v: 1e-3)
+    for _ in range(4):
+        shards.step()
+    comm.barrier()
+    shards.service()                                           # nothing left in any inbox
+    comm.barrier()
+    lo, hi = shards.bounds[rank]
+    own = {k: shards.slot_regions[rank][k].clone() for k in ("m", "v")}
+    own_p = shards.shards[rank].clone()
+    versions = shards.versions()
+    # without the gather the chief's arena holds no other owner's slots (the defect the gather is for)
+    blank_outside = float(rep.arena.full("slot:m")[shards.bounds[1][0]:].abs().max()) if rank == 0 else 0.0
+    prefix = None
+    if rank == 0:
+        shards.gather_state()
+        prefix = Saver(rep.arena, "adam").save(tmp, versions[0], versions[0])
+    prefix = comm.all_gather_object(prefix)[0]
+    shards.close()
+    comm.barrier()
+    # resume: fresh replicas restore the checkpoint; every owner's shard continues where it was
+    rep2 = TorchReplica("resnet", BATCH, num_residual_blocks=1, optimizer="adam")
+    rep2.load_batch(images, labels)
+    step = Saver(rep2.arena, "adam").restore(prefix)
+    shards2 = AsyncParameterShards(rep2, comm, board, 8, board_name + "_ps2", lambda v: 1e-3, start_version=step)
+    err = max(float((shards2.slot_regions[rank][k] - own[k]).abs().max()) for k in ("m", "v"))
+    err_p = float((shards2.shards[rank] - own_p).abs().max())
+    nonzero = float(own["m"].abs().sum())
+    v0 = shards2.versions()
+    comm.barrier()                      # nobody pushes before everybody has looked
+    shards2.step()
+    shards2.drain(60)
+    v1 = shards2.versions()
+    shards2.close()
+    comm.barrier()
+    comm.close()
+    return dict(err=err, err_p=err_p, nonzero=nonzero, versions=versions, step=step, v0=v0, v1=v1, blank_outside=blank_outside)
+
+
+def test_async_checkpoint_holds_every_owners_optimizer_state_and_resumes(tmp_path):
+    world = 2
+    out = run_workers(_async_ckpt_worker, world, f"dtf_t_asck_{os.getpid()}", str(tmp_path))
+    assert out[0]["blank_outside"] == 0.0
+    for o in out:
+        assert o["nonzero"] > 0 and o["err"] == 0.0 and o["err_p"] == 0.0      # every owner's m / v / parameters came back
+        assert o["step"] == o["versions"][0] == world * 4
+        assert o["v0"] == [o["step"]] * world                                  # shard versions continue at the restored step
+        assert o["v1"] == [o["step"] + world] * world                          # ... and count on from there
+
+
 def _sharded_ckpt_worker(rank, world, board_name, tmp):
     from distributed_tensorflow_amd.checkpoint.saver import Saver
     from distributed_tensorflow_amd.parallel.strategies import FullSync

@@ -77,6 +77,74 @@ def test_backup_update_is_the_mean_of_the_first_m_and_nobody_waits_for_the_strag
     assert out[0]["dt"] < 0.75 and out[2]["dt"] < 0.75, [o["dt"] for o in out]
 
 
+def _dead_closer_worker(rank, world, board_name):
+    import threading
+
+    from distributed_tensorflow_amd.ops import native as nv
+    from distributed_tensorflow_amd.ops import reference as ref
+    from distributed_tensorflow_amd.parallel.strategies import Backup
+
+    h = nv.hip()
+    comm, board, rep = _setup(rank, world, board_name, abortable=False)
+    rep.forward_backward()
+    rep.synchronize()
+    gathered = comm.all_gather_object(rep.arena.grads.detach().cpu().clone())
+    p0 = rep.arena.params.detach().cpu().clone()
+    strat = Backup(comm, board, 2)
+    log = strat._get_log(rep)
+    comm.barrier()
+
+    def open_word():
+        return int(h.ulog_peek(log._ctl[0], int(h.UW_OPEN), 1)[0])
+
+    def wait_for(pred, what):
+        deadline = time.time() + 30
+        while not pred(open_word()):
+            assert time.time() < deadline, what
+            time.sleep(0.002)
+
+    frozen = 1 << 31
+    dt, err, version = 0.0, 0.0, 0
+    if rank == 2:
+        # plays the replica whose arrival completes the quorum and which dies right after freezing the
+        # open word: gradient staged, word frozen with count 2 and mask {1, 2}, record never published
+        wait_for(lambda w: (w >> 16) & 0x7FFF == 1, "rank 1 never arrived")
+        h.memcpy_d2d(log._own_stage, rep.arena.grads.data_ptr(), log.total * 4, rep.stream.cuda_stream)
+        rep.synchronize()
+        h.ulog_poke(log._ctl[0], int(h.UW_OPEN), (0 << 32) | frozen | (2 << 16) | 0b110)
+    else:
+        if rank == 0:
+            wait_for(lambda w: bool(w & frozen), "the word was never frozen")   # arrives late: update 0 is full
+        # the watchdog's verdict, a second later, from another thread (the training stream is waiting)
+        threading.Timer(1.0, lambda: (torch.cuda.set_device(0), log.mark_dead(2))).start()
+        t0 = time.time()
+        res = log.contribute(1e-3, quorum=2, abort_at=0)
+        rep.synchronize()
+        dt = time.time() - t0
+        version = res.version
+        want = p0.clone()
+        ref.adam_update(want, (gathered[1] + gathered[2]) / 2, torch.zeros_like(want), torch.zeros_like(want), ref.adam_lr_t(1e-3, 1))
+        err = float((rep.arena.params.cpu() - want).abs().max())
+    entry = log.entry(0)
+    comm.barrier()
+    log.close()
+    comm.close()
+    return dict(dt=dt, err=err, version=version, entry=entry)
+
+
+def test_a_closer_that_dies_after_freezing_the_open_word_is_stood_in_for():
+    """The window between freezing the open word and publishing the closed record: the lowest live
+    contributor republishes the record from the frozen word once the dead replica is marked, and
+    sums the dead owner's shard; the survivors apply the update instead of timing out (20 s)."""
+    out = run_workers(_dead_closer_worker, 3, f"dtf_gu_dc_{os.getpid()}", timeout=300)
+    for r in (0, 1):
+        assert out[r]["version"] == 1 and out[r]["dt"] < 8.0, out[r]
+        assert out[r]["err"] < 1e-6, out[r]
+        count, mask, owners, scale = out[r]["entry"]
+        assert (count, mask, owners) == (2, 0b110, 0b110) and abs(scale - 0.5) < 1e-7
+    assert out[2]["entry"] is None          # nothing is written into a dead replica's block
+
+
 def _stress_worker(rank, world, board_name, m, steps):
     import random
 
@@ -300,3 +368,37 @@ def test_short_circuit_in_the_middle_of_backward_leaves_zeros_beyond_the_cut():
     times = sorted(e[4] for e in conv_cut)
     assert times[len(times) // 2] < 10.0 and times[-1] < 60.0, times[-3:]
     assert sum(e[4] for e in conv_cut) < 0.3 * sum(e[4] for e in conv_full)
+
+
+def test_abort_word_rising_in_the_middle_of_kernels_leaves_finite_gradients():
+    """The stop word is raised from another stream at varying points of a running step. A workgroup
+    takes the verdict once (thread 0, broadcast through LDS) and runs as a whole or not at all, so
+    whatever mix of workgroups ran, every gradient is a finite partial sum (soft-kill pushes it into
+    the shared update) - never the product of waves that ran on over LDS their workgroup's other
+    waves had not filled."""
+    from distributed_tensorflow_amd.ops import native as nv
+    from distributed_tensorflow_amd.train.replica import HipReplica
+
+    h = nv.hip()
+    rep = HipReplica("resnet", 256, num_residual_blocks=3, num_buckets=1, abortable=True)
+    g = torch.Generator().manual_seed(11)
+    rep.load_batch(torch.randn(256, 32, 32, 3, generator=g), torch.randint(0, 10, (256,), generator=g))
+    rep.forward_backward()
+    rep.synchronize()
+    full = rep.arena.grads.clone()
+    side = torch.cuda.Stream()
+    cut_somewhere = 0
+    for i in range(48):
+        h.ulog_poke(rep.ctl_block, int(h.UW_ABORT), 0)
+        torch.cuda.synchronize()
+        # a one-thread kernel on another stream that waits i * 20 us on the device, then raises the word:
+        # 0 .. 0.94 ms into a ~1 ms step
+        h.ulog_poke_async(rep.ctl_block, int(h.UW_ABORT), 1, i * 2000, side.cuda_stream)
+        rep.forward_backward()
+        torch.cuda.synchronize()
+        grads = rep.arena.grads
+        assert bool(torch.isfinite(grads).all()), i
+        assert float(grads.abs().max()) <= 4.0 * float(full.abs().max()) + 1.0, i
+        cut_somewhere += int(not torch.equal(grads, full) and float((grads - full).abs().max()) > 1e-3)
+    assert cut_somewhere >= 8          # the word did rise inside the step in a good share of the runs
+    h.ulog_poke(rep.ctl_block, int(h.UW_ABORT), 0)
