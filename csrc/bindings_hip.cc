@@ -86,13 +86,13 @@ PYBIND11_MODULE(_hip, m) {
     V(B); V(H); V(W); V(Cin); V(Ho); V(Wo); V(Cout);
     V(TH); V(TW); V(tiles_y); V(tiles_x);
     V(pad); V(stride); V(in_mode); a.in_bn = as_bn(d, "in_bn");
-    V(tiles_per_block); V(dw_slot_stride); V(co_tiles); V(debug_skip); P(dbg_stamps, unsigned long long);
+    V(tiles_per_block); V(dw_slot_stride); V(co_tiles); V(debug_skip); P(dbg_stamps, unsigned long long); P(dw_part, float);
     if (a.stride == 0) a.stride = 1;
     return conv_wgrad(a, ks, as_stream(stream));
   });
   m.def("conv_bwd_fused", [](const py::dict& d, uint64_t stream) {
     ConvBwdFusedArgs a{};
-    P(dy, const float); P(x, const float); P(wpk_t, const float); P(g, float); P(dw, float);
+    P(dy, const float); P(x, const float); P(wpk_t, const float); P(g, float); P(dw, float); P(dw_part, float);
     V(dw_slot_stride); a.bn = as_bn(d, "bn"); P(gsums, double); P(extra, const float);
     V(B); V(H); V(W); V(C);
     P(dy_x, const float); a.dy_bn = as_bn(d, "dy_bn"); P(dy_gsums, const double); P(dy_dgamma, float); P(dy_dbeta, float);
@@ -100,6 +100,30 @@ PYBIND11_MODULE(_hip, m) {
     P(tile_counters, int);
     return conv_bwd_fused(a, as_stream(stream));
   });
+  m.def("conv_bwd_fused_copies", [](const py::dict& d) {
+    ConvBwdFusedArgs a{};
+    P(dy, const float); P(x, const float); P(wpk_t, const float); P(g, float); P(dw, float);
+    a.bn = as_bn(d, "bn"); V(B); V(H); V(W); V(C);
+    P(dy_x, const float); a.dy_bn = as_bn(d, "dy_bn"); P(dy_gsums, const double);
+    P(dy_res, const float); P(dy_out, float); V(dy_res_mode);
+    return conv_bwd_fused_copies(a);
+  });
+  m.def("conv_wgrad_band_copies", [](const py::dict& d, int ks) {
+    ConvWgradArgs a{};
+    V(B); V(H); V(W); V(Cin); V(Ho); V(Wo); V(Cout); V(pad); V(stride); V(tiles_per_block); V(co_tiles);
+    if (a.stride == 0) a.stride = 1;
+    return conv_wgrad_band_copies(a, ks);
+  });
+  m.def("conv_stem_wgrad_copies", [](const py::dict& d) {
+    ConvStemArgs a{};
+    V(B); P(dy_x, const float);
+    return conv_stem_wgrad_copies(a);
+  });
+  m.def("part_reduce", [](uint64_t table, int n_entries, int total_items, uint64_t slots, long long slot_stride, uint64_t stream) {
+    PartReduceArgs a{reinterpret_cast<const PartEntry*>(table), n_entries, reinterpret_cast<float*>(slots), slot_stride};
+    part_reduce(a, total_items, as_stream(stream));
+  });
+  m.attr("PART_ENTRY_BYTES") = (int)sizeof(PartEntry);
   m.def("conv_bwd_fused_supported", &conv_bwd_fused_supported);
   m.def("conv_stem_fwd", [](const py::dict& d, uint64_t stream) {
     ConvStemArgs a{};
@@ -108,7 +132,7 @@ PYBIND11_MODULE(_hip, m) {
   });
   m.def("conv_stem_wgrad", [](const py::dict& d, uint64_t stream) {
     ConvStemArgs a{};
-    P(x, const float); P(dy, const float); P(dw, float); V(slot_stride); V(B);
+    P(x, const float); P(dy, const float); P(dw, float); P(dw_part, float); V(slot_stride); V(B);
     P(dy_x, const float); a.dy_bn = as_bn(d, "dy_bn"); P(dy_gsums, const double); P(dy_dgamma, float); P(dy_dbeta, float);
     conv_stem_wgrad(a, as_stream(stream));
   });

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(BnStatsArgs a) {
   }
   __syncthreads();
   double* slot = stat_slot(a.sums, C);
-  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) atomicAdd(&slot[c], (double)red[c]);
+  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) atomicAdd(&slot[c], to_grid((double)red[c], kStatGridFwd));
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(BnReluBwdReduce
   }
   __syncthreads();
   double* slot = stat_slot(a.gsums, C);
-  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) atomicAdd(&slot[c], (double)red[c]);
+  for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) atomicAdd(&slot[c], to_grid((double)red[c], kStatGridBwd));
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdApplyArgs a) {

@@ -70,6 +70,17 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Statistics leave a workgroup as fp64 atomics, and fp64 addition is not associative: the last bits
+// of a total would depend on the order in which the workgroups arrive. Each contribution is therefore
+// rounded to a fixed grid first (multiples of 1 / scale): sums of grid points are exact in fp64 as
+// long as they stay below 2^53 grid steps, so the total is the same whatever the order - and beyond
+// that range the additions are merely rounded like any other, nothing overflows. Forward statistics
+// (sums of activations and of their squares: up to ~1e9 over a batch) use steps of 2^-20, the
+// backward sums (gradients: ~1e-3) steps of 2^-44.
+constexpr double kStatGridFwd = 1048576.0;                  // 2^20
+constexpr double kStatGridBwd = 17592186044416.0;           // 2^44
+__device__ __forceinline__ double to_grid(double s, double scale) { return rint(s * scale) * (1.0 / scale); }
+
 // Block-level flush of per-channel statistics held as per-lane partials in the swapped-operand
 // accumulator layout (lane (q, l15), register r <-> channel 16*j + 4*q + r, pixel l15): reduce over
 // the 16 pixel lanes, park one row per wave in `scratch` (WAVES * 2 * NT*16 floats that nobody
@@ -79,7 +90,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // last bits between runs, enough to flip the ReLU mask of an activation within rounding of zero.
 template <int NT, int WAVES>
 __device__ __forceinline__ void block_stat_flush(float* scratch, const floatx4 (&st1)[NT], const floatx4 (&st2)[NT],
-                                                 double* sums, int C, int c_first) {
+                                                 double* sums, int C, int c_first, double grid) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -108,7 +119,7 @@ __device__ __forceinline__ void block_stat_flush(float* scratch, const floatx4 (
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) s += (double)scratch[(w * 2 + which) * NT * 16 + c];
-    if (c_first + c < C) atomicAdd(&stat_slot(sums, C)[which * C + c_first + c], s);
+    if (c_first + c < C) atomicAdd(&stat_slot(sums, C)[which * C + c_first + c], to_grid(s, grid));
   }
 }
 

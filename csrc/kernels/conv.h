@@ -96,6 +96,11 @@ struct ConvWgradArgs {
   int tiles_per_block;   // tiles of the flattened (image, tile) sequence walked by one block
   float* dbias;          // nullable: [Cout] += sum of dout (LeNet bias gradient)
   long long dw_slot_stride;  // floats between the per-XCD copies of dw (0: one copy)
+  // Band kernel only, non-null: no atomics. Workgroup b of a cout block stores its part of the sum
+  // into copy b of conv_wgrad_band_copies() copies of the whole filter gradient, `dw_part` + b * ks*ks*Cin*Cout
+  // (the cout blocks fill disjoint columns of a copy; every element of every copy is written);
+  // part_reduce adds the copies up in a fixed order, so the gradient has the same bits on every run.
+  float* dw_part;
   int co_tiles;          // 16-channel output tiles per block (0: chosen by the launcher)
   int debug_skip;        // timing experiments only: 1 = no MFMA, 2 = no loads, 4 = no flush
   unsigned long long* dbg_stamps;  // timing experiments only: [blocks][16] wall-clock stamps of thread 0
@@ -104,6 +109,8 @@ struct ConvWgradArgs {
 size_t conv_wgrad(ConvWgradArgs a, int ks, hipStream_t stream);
 // Band-tiled persistent variant for the 3x3 ResNet shapes; returns 0 when the shape is not covered.
 size_t conv_wgrad_band(const ConvWgradArgs& a, int ks, hipStream_t stream);
+// Copies of the filter gradient that call would fill through `dw_part` (0: shape not covered).
+int conv_wgrad_band_copies(const ConvWgradArgs& a, int ks);
 
 
 // Whole backward pass of one stride-1 3x3 layer y = conv(relu(bn(x)), W) in one kernel:
@@ -117,6 +124,10 @@ struct ConvBwdFusedArgs {
   float* g;              // [B,H,W,C]
   float* dw;             // [3,3,C,C] HWIO, copy 0 of kStatSlots copies
   long long dw_slot_stride;
+  // Non-null: no atomics (see ConvWgradArgs::dw_part). The workgroups that share a tile sequence
+  // (one per channel split) fill copy j of conv_bwd_fused_copies() copies of the whole [3,3,C,C]
+  // gradient with plain stores; part_reduce sums the copies in a fixed order.
+  float* dw_part;
   BnRef bn;              // BatchNorm of x
   double* gsums;         // [kStatSlots][2*C], nullable
   const float* extra;    // [B,H,W,C] gradient added before masking, nullable
@@ -152,6 +163,7 @@ struct ConvBwdFusedArgs {
 constexpr int kBwdTileCounters = 32;   // 8 XCDs x up to 4 channel splits
 bool conv_bwd_fused_supported(int B, int H, int W, int C);
 size_t conv_bwd_fused(const ConvBwdFusedArgs& a, hipStream_t stream);
+int conv_bwd_fused_copies(const ConvBwdFusedArgs& a);
 
 // ---- stem of the CIFAR ResNet: 3x3, 3 -> 16 channels, SAME, 32x32 images (conv_stem.hip)
 // forward: y = conv(x, w), sums (nullable) += per-channel (sum, sum of squares) of y in the
@@ -164,6 +176,7 @@ struct ConvStemArgs {
   double* sums;      // [kStatSlots][32], forward, nullable
   const float* dy;   // [B,32,32,16], gradient
   float* dw;         // [27][16], gradient
+  float* dw_part;    // gradient, non-null: workgroup b stores its sum at dw_part + b * 432 instead (conv_stem_wgrad_copies() copies)
   int slot_stride;
   int B;
   // Optional BatchNorm-backward prologue of the gradient kernel (as ConvBwdFusedArgs::dy_x): `dy`
@@ -180,6 +193,7 @@ struct ConvStemArgs {
 bool conv_stem_supported(int H, int W, int Cin, int Cout, int ks, int stride);
 void conv_stem_fwd(const ConvStemArgs& a, hipStream_t stream);
 void conv_stem_wgrad(const ConvStemArgs& a, hipStream_t stream);
+int conv_stem_wgrad_copies(const ConvStemArgs& a);
 
 // ---- 5x5 stride-1 SAME convolution over 14x14 maps, whole images per workgroup (conv5x5_tile.hip)
 // Forward form (flip = 0): Cin 32 -> Cout 64, y = relu(conv(x, w) + bias), w = conv5x5_pack of

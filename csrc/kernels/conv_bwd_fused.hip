@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
   }
 
   // ---- statistics (the filter slice in LDS is no longer needed: its space parks the wave rows) ------
-  if (a.gsums) block_stat_flush<NT, 4>(s_w, st1, st2, a.gsums, C, c0);
+  if (a.gsums) block_stat_flush<NT, 4>(s_w, st1, st2, a.gsums, C, c0, kStatGridBwd);
   // ---- filter gradient flush: accumulators -> LDS, sum the pixel-split partials, coalesced atomics ----
   constexpr int RS = G::RED_STRIDE;
   float* s_red = smem;   // [WX][9][XC][RS]; the tile buffers are free (barrier above)
@@ -440,7 +440,8 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
     for (int r = 0; r < 4; ++r)
       s_red[((wx * 9 + tap) * XC + ci_t * 16 + 4 * q + r) * RS + co_t * 16 + l15] = accw[tap][r];
   __syncthreads();
-  float* dw = a.dw + (size_t)(blockIdx.x & (kStatSlots - 1)) * a.dw_slot_stride;
+  // with dw_part: plain stores into copy jblk of the whole gradient (this block's rows of it)
+  float* dw = a.dw_part ? a.dw_part + (size_t)jblk * (9 * C * C) : a.dw + (size_t)(blockIdx.x & (kStatSlots - 1)) * a.dw_slot_stride;
   for (int e = tid; e < 9 * XC * C; e += 256) {
     const int col = e % C;
     const int row = (e / C) % XC;
@@ -448,12 +449,16 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_fused_kernel(ConvBwdFusedArgs
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < WX; ++w) v += s_red[((w * 9 + tap) * XC + row) * RS + col];
-    atomicAdd(dw + ((size_t)tap * C + c0 + row) * C + col, v);
+    float* dst = dw + ((size_t)tap * C + c0 + row) * C + col;
+    if (a.dw_part) *dst = v;
+    else atomicAdd(dst, v);
   }
 }
 
+// copies != nullptr: no launch, *copies = workgroups per channel split (= copies of the gradient
+// filled through ConvBwdFusedArgs::dw_part)
 template <int C, int NT, int TW, int TH, bool DYBN, int RES = 0>
-size_t launch_bf(const ConvBwdFusedArgs& a, hipStream_t stream) {
+size_t launch_bf(const ConvBwdFusedArgs& a, hipStream_t stream, int* copies) {
   using G = BF<C, NT, TW, TH>;
   const size_t shmem = (size_t)G::LDS_FLOATS * sizeof(float);
   constexpr int zsplit = (C / 16) / NT;
@@ -473,6 +478,10 @@ size_t launch_bf(const ConvBwdFusedArgs& a, hipStream_t stream) {
   const int iters = ceil_div(total_tiles, gpz_max);
   int gpz = ceil_div(total_tiles, iters);
   gpz = (gpz + 7) / 8 * 8;
+  if (copies) {
+    *copies = gpz;
+    return 0;
+  }
   launch("conv_bwd_fused", conv_bwd_fused_kernel<C, NT, TW, TH, DYBN, RES>, dim3(gpz * zsplit), dim3(256), shmem, stream, a);
   return shmem;
 }
@@ -484,7 +493,7 @@ bool conv_bwd_fused_supported(int B, int H, int W, int C) {
   return H == W && H % 8 == 0 && ((C == 16 && W == 32) || (C == 32 && W == 16) || (C == 64 && W == 8));
 }
 
-size_t conv_bwd_fused(const ConvBwdFusedArgs& a, hipStream_t stream) {
+static size_t bf_dispatch(const ConvBwdFusedArgs& a, hipStream_t stream, int* copies) {
   if (!conv_bwd_fused_supported(a.B, a.H, a.W, a.C)) throw std::runtime_error("conv_bwd_fused: unsupported shape");
   if (!a.dy || !a.x || !a.wpk_t || !a.g || !a.dw || !a.bn.sums) throw std::runtime_error("conv_bwd_fused: null operand");
   if (a.dy_x) {
@@ -492,21 +501,29 @@ size_t conv_bwd_fused(const ConvBwdFusedArgs& a, hipStream_t stream) {
     if (a.dy_res) {
       if (!a.dy_out) throw std::runtime_error("conv_bwd_fused: dy_res needs dy_out");
       if (a.dy_res_mode == 1) {
-        if (a.C == 16) return launch_bf<16, 1, 32, 4, true, 2>(a, stream);
-        if (a.C == 32) return launch_bf<32, 1, 16, 8, true, 2>(a, stream);
+        if (a.C == 16) return launch_bf<16, 1, 32, 4, true, 2>(a, stream, copies);
+        if (a.C == 32) return launch_bf<32, 1, 16, 8, true, 2>(a, stream, copies);
         throw std::runtime_error("conv_bwd_fused: no option-A shortcut behind a 64-channel stage");
       }
-      if (a.C == 16) return launch_bf<16, 1, 32, 4, true, 1>(a, stream);
-      if (a.C == 32) return launch_bf<32, 1, 16, 8, true, 1>(a, stream);
-      return launch_bf<64, 1, 8, 8, true, 1>(a, stream);
+      if (a.C == 16) return launch_bf<16, 1, 32, 4, true, 1>(a, stream, copies);
+      if (a.C == 32) return launch_bf<32, 1, 16, 8, true, 1>(a, stream, copies);
+      return launch_bf<64, 1, 8, 8, true, 1>(a, stream, copies);
     }
-    if (a.C == 16) return launch_bf<16, 1, 32, 8, true>(a, stream);
-    if (a.C == 32) return launch_bf<32, 1, 16, 8, true>(a, stream);
-    return launch_bf<64, 1, 8, 8, true>(a, stream);
+    if (a.C == 16) return launch_bf<16, 1, 32, 8, true>(a, stream, copies);
+    if (a.C == 32) return launch_bf<32, 1, 16, 8, true>(a, stream, copies);
+    return launch_bf<64, 1, 8, 8, true>(a, stream, copies);
   }
-  if (a.C == 16) return launch_bf<16, 1, 32, 8, false>(a, stream);
-  if (a.C == 32) return launch_bf<32, 1, 16, 8, false>(a, stream);
-  return launch_bf<64, 1, 8, 8, false>(a, stream);
+  if (a.C == 16) return launch_bf<16, 1, 32, 8, false>(a, stream, copies);
+  if (a.C == 32) return launch_bf<32, 1, 16, 8, false>(a, stream, copies);
+  return launch_bf<64, 1, 8, 8, false>(a, stream, copies);
+}
+
+size_t conv_bwd_fused(const ConvBwdFusedArgs& a, hipStream_t stream) { return bf_dispatch(a, stream, nullptr); }
+
+int conv_bwd_fused_copies(const ConvBwdFusedArgs& a) {
+  int copies = 0;
+  bf_dispatch(a, nullptr, &copies);
+  return copies;
 }
 
 }  // namespace dtf

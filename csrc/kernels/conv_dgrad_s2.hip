@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_kernel(ConvFpropArgs a) 
     __syncthreads();
   }
 
-  if (a.out_sums) block_stat_flush<NT, 4>(smem, st1, st2, a.out_sums, a.Cout, z * NT * 16);
+  if (a.out_sums) block_stat_flush<NT, 4>(smem, st1, st2, a.out_sums, a.Cout, z * NT * 16, kStatGridBwd);
 }
 
 template <int CP, int NT, int TW, int TH>

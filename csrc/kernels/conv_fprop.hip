@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(ConvFpropArgs a) {
 
   // ---- statistics: reduce over the 16 pixel lanes, then waves (LDS), then blocks (fp64 atomics)
   if (a.out_sums) {
-    block_stat_flush<NT, 4>(smem, st1, st2, a.out_sums, a.Cout, z * NT * 16);
+    block_stat_flush<NT, 4>(smem, st1, st2, a.out_sums, a.Cout, z * NT * 16, a.epi_mode == EPI_MASK ? kStatGridBwd : kStatGridFwd);
   }
 }
 

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_band_kernel(ConvFpropArgs a
   }
 
   if (a.out_sums && !(DTF_DEBUG_SKIP(a) & 8)) {
-    block_stat_flush<NT, 4>(smem, st1, st2, a.out_sums, a.Cout, z * NT * 16);
+    block_stat_flush<NT, 4>(smem, st1, st2, a.out_sums, a.Cout, z * NT * 16, BWD ? kStatGridBwd : kStatGridFwd);
   }
 }
 

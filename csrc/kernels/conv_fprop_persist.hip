@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256, (CP <= 16 && NT == 1) ? 3 : 2) void conv_fprop
 
   DTF_STAMP(14);
   if (a.out_sums && !(a.debug_skip & 8)) {
-    block_stat_flush<NT, 4>(smem, st1, st2, a.out_sums, a.Cout, z * NT * 16);
+    block_stat_flush<NT, 4>(smem, st1, st2, a.out_sums, a.Cout, z * NT * 16, a.epi_mode == EPI_MASK ? kStatGridBwd : kStatGridFwd);
   }
   DTF_STAMP(15);
 #undef DTF_STAMP

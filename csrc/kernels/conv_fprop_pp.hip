@@ -370,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void conv_fprop_pp_kernel(ConvFpropArgs a) 
   }
 
   if (a.out_sums) {
-    block_stat_flush<NT, 8>(smem, st1, st2, a.out_sums, a.Cout, z * NT * 16);
+    block_stat_flush<NT, 8>(smem, st1, st2, a.out_sums, a.Cout, z * NT * 16, BWD ? kStatGridBwd : kStatGridFwd);
   }
 }
 

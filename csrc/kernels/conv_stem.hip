@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(ConvStemArgs a) {
       *reinterpret_cast<floatx4*>(yb + (size_t)p * 16) = acc;
     }
   }
-  if (a.sums) block_stat_flush<1, 4>(scratch, st1, st2, a.sums, 16, 0);
+  if (a.sums) block_stat_flush<1, 4>(scratch, st1, st2, a.sums, 16, 0, kStatGridFwd);
 }
 
 // dw[k][co] += sum over pixels x[window element k of the pixel] * dy[pixel][co]
@@ -219,12 +219,15 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(ConvStemArgs a) {
     red[wave][1][i][lane] = acc1[i];
   }
   __syncthreads();
-  float* dw = a.dw + (a.slot_stride ? (size_t)(blockIdx.x & (kStatSlots - 1)) * a.slot_stride : 0);
+  float* dw = a.dw_part ? a.dw_part + (size_t)blockIdx.x * 432 : a.dw + (a.slot_stride ? (size_t)(blockIdx.x & (kStatSlots - 1)) * a.slot_stride : 0);
   for (int e = tid; e < 2 * 4 * 64; e += 256) {
     const int l = e & 63, i = (e >> 6) & 3, t = e >> 8;
     const int k = 16 * t + 4 * (l >> 4) + i, co = l & 15;
     const float s = (red[0][t][i][l] + red[1][t][i][l]) + (red[2][t][i][l] + red[3][t][i][l]);
-    if (k < 27 && s != 0.f) atomicAdd(dw + k * 16 + co, s);
+    if (k < 27) {
+      if (a.dw_part) dw[k * 16 + co] = s;            // plain stores: every element of the copy is written
+      else if (s != 0.f) atomicAdd(dw + k * 16 + co, s);
+    }
   }
 }
 
@@ -252,16 +255,28 @@ void conv_stem_fwd(const ConvStemArgs& a, hipStream_t stream) {
   launch("conv_stem_fwd", conv_stem_fwd_kernel, dim3(stem_grid(4 * a.B, 256 * (bpc > 4 ? 4 : bpc))), dim3(256), 0, stream, a);
 }
 
-void conv_stem_wgrad(const ConvStemArgs& a, hipStream_t stream) {
-  if (a.B < 1 || !a.x || !a.dy || !a.dw) throw std::runtime_error("conv_stem_wgrad: null operand or empty batch");
+static int stem_wgrad_grid(const ConvStemArgs& a) {
   if (a.dy_x) {
-    if (!a.dy_bn.sums || !a.dy_bn.gamma || !a.dy_gsums) throw std::runtime_error("conv_stem_wgrad: the BatchNorm prologue needs its statistics");
     static const int bpc = stem_blocks_per_cu(conv_stem_wgrad_kernel<true>);
-    launch("conv_stem_wgrad", conv_stem_wgrad_kernel<true>, dim3(stem_grid(4 * a.B, 256 * (bpc > 2 ? 2 : bpc))), dim3(256), 0, stream, a);
-    return;
+    return stem_grid(4 * a.B, 256 * (bpc > 2 ? 2 : bpc));
   }
   static const int bpc = stem_blocks_per_cu(conv_stem_wgrad_kernel<false>);
-  launch("conv_stem_wgrad", conv_stem_wgrad_kernel<false>, dim3(stem_grid(4 * a.B, 256 * (bpc > 2 ? 2 : bpc))), dim3(256), 0, stream, a);
+  return stem_grid(4 * a.B, 256 * (bpc > 2 ? 2 : bpc));
+}
+
+int conv_stem_wgrad_copies(const ConvStemArgs& a) {
+  if (a.B < 1) throw std::runtime_error("conv_stem_wgrad: empty batch");
+  return stem_wgrad_grid(a);
+}
+
+void conv_stem_wgrad(const ConvStemArgs& a, hipStream_t stream) {
+  if (a.B < 1 || !a.x || !a.dy || !(a.dw || a.dw_part)) throw std::runtime_error("conv_stem_wgrad: null operand or empty batch");
+  if (a.dy_x) {
+    if (!a.dy_bn.sums || !a.dy_bn.gamma || !a.dy_gsums) throw std::runtime_error("conv_stem_wgrad: the BatchNorm prologue needs its statistics");
+    launch("conv_stem_wgrad", conv_stem_wgrad_kernel<true>, dim3(stem_wgrad_grid(a)), dim3(256), 0, stream, a);
+    return;
+  }
+  launch("conv_stem_wgrad", conv_stem_wgrad_kernel<false>, dim3(stem_wgrad_grid(a)), dim3(256), 0, stream, a);
 }
 
 }  // namespace dtf

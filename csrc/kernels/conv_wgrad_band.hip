@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(ConvWgradArgs a
         s_red[((wx * 9 + tap) * ROWS + ci_t * 16 + 4 * q + r) * RS + co_t * 16 + l15] = acc[tap][k][r];
     }
   __syncthreads();
-  float* dw = a.dw + (size_t)(blockIdx.x & (kStatSlots - 1)) * a.dw_slot_stride;
+  float* dw = a.dw_part ? a.dw_part + (size_t)bx * (9 * a.Cin * a.Cout) : a.dw + (size_t)(blockIdx.x & (kStatSlots - 1)) * a.dw_slot_stride;
   for (int e = tid; e < 9 * ROWS * CO_B; e += 256) {
     const int col = e % CO_B;
     const int row = (e / CO_B) % ROWS;
@@ -246,12 +246,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_band_kernel(ConvWgradArgs a
 #pragma unroll
     for (int w = 0; w < WX; ++w) v += s_red[((w * 9 + tap) * ROWS + row) * RS + col];
     const int co = co_blk0 + col;
-    if (row < a.Cin && co < a.Cout) atomicAdd(dw + ((size_t)tap * a.Cin + row) * a.Cout + co, v);
+    if (row < a.Cin && co < a.Cout) {
+      float* dst = dw + ((size_t)tap * a.Cin + row) * a.Cout + co;
+      if (a.dw_part) *dst = v;
+      else atomicAdd(dst, v);
+    }
   }
 }
 
 template <int S, int CP, int CO_T, int TW, int TH>
-size_t launch_band(ConvWgradArgs a, hipStream_t stream) {
+size_t launch_band(ConvWgradArgs a, hipStream_t stream, int* copies) {
   using G = BandGeom<S, CP, CO_T, TW, TH>;
   const size_t shmem = (size_t)G::LDS_FLOATS * sizeof(float);
   const int gy = ceil_div(ceil_div(a.Cout, 16), CO_T);
@@ -263,6 +267,10 @@ size_t launch_band(ConvWgradArgs a, hipStream_t stream) {
   gx = (gx + 7) / 8 * 8;   // keeps (blockIdx.x % 8) equal for the blocks of one XCD across cout blocks
   if (gx > total) gx = total;
   a.tiles_per_block = gx;  // the kernel reads the number of blocks per cout block from this field
+  if (copies) {
+    *copies = gx;
+    return 1;
+  }
   launch("conv_wgrad_band", conv_wgrad_band_kernel<S, CP, CO_T, TW, TH>, dim3(gx * gy), dim3(256), shmem, stream, a);
   return shmem;
 }
@@ -270,7 +278,7 @@ size_t launch_band(ConvWgradArgs a, hipStream_t stream) {
 }  // namespace
 
 // Returns 0 when the shape is not covered (the caller falls back to the general kernel).
-size_t conv_wgrad_band(const ConvWgradArgs& a, int ks, hipStream_t stream) {
+static size_t band_dispatch(const ConvWgradArgs& a, int ks, hipStream_t stream, int* copies) {
   if (ks != 3 || a.dbias != nullptr || a.pad > 1 || (a.Cin & 15) || (a.Cout & 15)) return 0;
   if (a.Ho != a.Wo || a.H != a.W || a.H != a.Ho * a.stride) return 0;
   const int nt = a.Cout / 16;
@@ -279,8 +287,8 @@ size_t conv_wgrad_band(const ConvWgradArgs& a, int ks, hipStream_t stream) {
   if (a.stride == S_ && a.Cin == CIN_ && a.Wo == TW_ && a.Ho % TH_ == 0) {                         \
     if (co_t <= 0) co_t = CO_DEFAULT;                                                              \
     if (nt % co_t) return 0;                                                                       \
-    if (co_t == 1) return launch_band<S_, CIN_, 1, TW_, TH_>(a, stream);                           \
-    if (co_t == 2) return launch_band<S_, CIN_, 2, TW_, TH_>(a, stream);                           \
+    if (co_t == 1) return launch_band<S_, CIN_, 1, TW_, TH_>(a, stream, copies);                   \
+    if (co_t == 2) return launch_band<S_, CIN_, 2, TW_, TH_>(a, stream, copies);                   \
     return 0;                                                                                      \
   }
   DTF_BAND(1, 16, 32, 8, 1)
@@ -290,6 +298,13 @@ size_t conv_wgrad_band(const ConvWgradArgs& a, int ks, hipStream_t stream) {
   DTF_BAND(1, 64, 8, 8, 1)
 #undef DTF_BAND
   return 0;
+}
+
+size_t conv_wgrad_band(const ConvWgradArgs& a, int ks, hipStream_t stream) { return band_dispatch(a, ks, stream, nullptr); }
+
+int conv_wgrad_band_copies(const ConvWgradArgs& a, int ks) {
+  int copies = 0;
+  return band_dispatch(a, ks, nullptr, &copies) ? copies : 0;
 }
 
 }  // namespace dtf

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
   DTF_ABORT_GUARD(a);
   __shared__ float s_scale[kMaxC], s_shift[kMaxC], s_mean[kMaxC], s_rstd[kMaxC];
   __shared__ float s_w[kMaxC * kMaxK / 4];
-  __shared__ float s_red[2 * kMaxC];
+  __shared__ float s_red[kHeadImgs][2 * kMaxC];   // one row per wave, combined in wave order: no float atomics
   const int C = a.C, C4 = C >> 2, K = a.K, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.x * kHeadImgs + wave;
@@ -137,8 +137,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
   const float* fw = w_in_lds ? s_w : a.fc_w;
   for (int c = tid; c < C; c += 256) {
     bn_coeffs(a.bn, c, C, s_scale[c], s_shift[c], s_mean[c], s_rstd[c]);
-    s_red[c] = 0.f;
-    s_red[C + c] = 0.f;
+#pragma unroll
+    for (int w = 0; w < kHeadImgs; ++w) {
+      s_red[w][c] = 0.f;
+      s_red[w][C + c] = 0.f;
+    }
   }
   __syncthreads();
   if (live) {
@@ -176,36 +179,52 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
     if (lane < C4) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        atomicAdd(&s_red[c + e], s1[e]);
-        atomicAdd(&s_red[C + c + e], s2[e]);
+        s_red[wave][c + e] = s1[e];
+        s_red[wave][C + c + e] = s2[e];
       }
     }
   }
   __syncthreads();
   double* slot = stat_slot(a.gsums, C);
-  for (int cc = tid; cc < 2 * C; cc += 256) atomicAdd(&slot[cc], (double)s_red[cc]);
+  for (int cc = tid; cc < 2 * C; cc += 256) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kHeadImgs; ++w) s += (double)s_red[w][cc];
+    atomicAdd(&slot[cc], to_grid(s, kStatGridBwd));
+  }
 }
 
-// FC parameter gradients: one thread per (c, k) element walks the batch; dW[c][k] = sum_n
-// feat[n][c] * dz[n][k], db[k] = sum_n dz[n][k]. The batch is split over gridDim.y blocks that
-// combine with one atomic per element.
+// FC parameter gradients dW[c][k] = sum_n feat[n][c] * dz[n][k], db[k] = sum_n dz[n][k]: a workgroup
+// owns 16 elements; thread (element, split) walks a sixteenth of the batch, the sixteen partial sums
+// of an element are added in split order and the result is stored - no atomics, so the gradient has
+// the same bits on every run.
+constexpr int kParamElems = 16, kParamSplits = 16;
 __global__ __launch_bounds__(256) void head_param_grad_kernel(HeadBwdArgs a) {
   DTF_ABORT_GUARD(a);
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float part[kParamSplits][kParamElems + 1];
+  const int el = threadIdx.x & (kParamElems - 1), sp = threadIdx.x / kParamElems;
+  const int e = blockIdx.x * kParamElems + el;
   const int C = a.C, K = a.K;
-  const int per = (a.B + gridDim.y - 1) / gridDim.y;
-  const int n0 = blockIdx.y * per;
+  const int per = (a.B + kParamSplits - 1) / kParamSplits;
+  const int n0 = sp * per;
   const int n1 = (n0 + per < a.B) ? n0 + per : a.B;
+  float s = 0.f;
   if (e < C * K) {
     const int c = e / K, k = e - c * K;
-    float s = 0.f;
     for (int n = n0; n < n1; ++n) s += a.feat[(size_t)n * C + c] * a.dlogits[(size_t)n * K + k];
-    atomicAdd(&a.d_fc_w[e], s);
   } else if (e < C * K + K) {
     const int k = e - C * K;
-    float s = 0.f;
     for (int n = n0; n < n1; ++n) s += a.dlogits[(size_t)n * K + k];
-    atomicAdd(&a.d_fc_b[k], s);
+  }
+  part[sp][el] = s;
+  __syncthreads();
+  if (threadIdx.x < kParamElems) {
+    const int e2 = blockIdx.x * kParamElems + threadIdx.x;
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < kParamSplits; ++p) t += part[p][threadIdx.x];
+    if (e2 < C * K) a.d_fc_w[e2] += t;
+    else if (e2 < C * K + K) a.d_fc_b[e2 - C * K] += t;
   }
 }
 
@@ -258,11 +277,7 @@ void head_bwd(const HeadBwdArgs& a, hipStream_t stream) {
   if (a.K > kMaxK || a.C > kMaxC || (a.C & 3) || (64 % (a.C / 4)) != 0)
     throw std::runtime_error("head_bwd: unsupported C/K");
   launch("head_bwd", head_bwd_kernel, dim3(ceil_div(a.B, kHeadImgs)), dim3(256), 0, stream, a);
-  // ~16 samples per thread: the loop is a chain of dependent loads, so depth, not atomics, sets its time
-  int splits = a.B / 16;
-  if (splits < 1) splits = 1;
-  if (splits > 128) splits = 128;
-  launch("head_param_grad", head_param_grad_kernel, dim3(ceil_div(a.C * a.K + a.K, 256), splits), dim3(256), 0, stream, a);
+  launch("head_param_grad", head_param_grad_kernel, dim3(ceil_div(a.C * a.K + a.K, kParamElems)), dim3(256), 0, stream, a);
 }
 
 void softmax_xent(const SoftmaxXentArgs& a, hipStream_t stream) {

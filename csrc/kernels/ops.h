@@ -169,6 +169,21 @@ void flat_axpy(const AxpyArgs& a, hipStream_t stream);         // y += alpha*x
 // copies, see ConvWgradArgs::dw_slot_stride); the copies are zeroed where they held anything.
 struct SlotReduceArgs { float* y; float* slots; long long n; long long slot_stride; };
 void slot_reduce(const SlotReduceArgs& a, hipStream_t stream);
+// Fixed-order sum of per-workgroup gradient copies (ConvBwdFusedArgs::dw_part and friends), all
+// tensors of a gradient bucket in one launch: slots[k][dst_off + i] = part[k][i] + part[k + 8][i] +
+// part[k + 16][i] + ... for k < kStatSlots, stored (not added); slot_reduce then adds the eight
+// slots in its own fixed order. Nothing depends on which workgroup finished first, so two runs
+// from the same state produce the same bits.
+struct PartEntry {
+  const float* part;     // [copies][4 * numel4]
+  long long dst_off;     // float offset of the tensor inside a slot (multiple of 4)
+  int copies;
+  int numel4;            // float4s per copy
+  int first_item;        // work items of the entries before this one
+  int pad;
+};
+struct PartReduceArgs { const PartEntry* table; int n_entries; float* slots; long long slot_stride; };
+void part_reduce(const PartReduceArgs& a, int total_items, hipStream_t stream);
 // y[0:n] += sum over p < parts of ws[p*stride + (0:n)] (per-workgroup partial results written with
 // plain stores; n and stride multiples of 4).
 struct PartialSumArgs { float* y; const float* ws; long long n; int parts; long long stride; AbortRef abort; };

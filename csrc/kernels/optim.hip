@@ -101,6 +101,34 @@ __global__ __launch_bounds__(256) void axpy_kernel(AxpyArgs a) {
   if (gi < a.n - tail0) a.y[tail0 + gi] += a.alpha * a.x[tail0 + gi];
 }
 
+// One work item = (tensor, chunk of 256 float4s, slot k): the copies k, k + 8, k + 16, ... of the chunk
+// are added in that order - loads issued four at a time, additions strictly sequential.
+__global__ __launch_bounds__(256) void part_reduce_kernel(PartReduceArgs a) {
+  int e = 0;
+  while (e + 1 < a.n_entries && (int)blockIdx.x >= a.table[e + 1].first_item) ++e;
+  const PartEntry ent = a.table[e];
+  const int local = (int)blockIdx.x - ent.first_item;
+  const int k = local & (kStatSlots - 1);
+  const int idx4 = (local >> 3) * 256 + (int)threadIdx.x;
+  if (idx4 >= ent.numel4) return;
+  const floatx4* p = reinterpret_cast<const floatx4*>(ent.part) + idx4;
+  const size_t cs = (size_t)ent.numel4;
+  floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+  int j = k;
+  for (; j + 3 * kStatSlots < ent.copies; j += 4 * kStatSlots) {
+    const floatx4 v0 = __builtin_nontemporal_load(p + (size_t)j * cs);
+    const floatx4 v1 = __builtin_nontemporal_load(p + (size_t)(j + kStatSlots) * cs);
+    const floatx4 v2 = __builtin_nontemporal_load(p + (size_t)(j + 2 * kStatSlots) * cs);
+    const floatx4 v3 = __builtin_nontemporal_load(p + (size_t)(j + 3 * kStatSlots) * cs);
+    acc += v0;
+    acc += v1;
+    acc += v2;
+    acc += v3;
+  }
+  for (; j < ent.copies; j += kStatSlots) acc += __builtin_nontemporal_load(p + (size_t)j * cs);
+  reinterpret_cast<floatx4*>(a.slots + (size_t)k * a.slot_stride + ent.dst_off)[idx4] = acc;
+}
+
 // y[i] += sum over the kStatSlots copies of x; the copies are cleared for the next step.
 __global__ __launch_bounds__(256) void slot_reduce_kernel(SlotReduceArgs a) {
   const long long n4 = a.n >> 2;
@@ -168,6 +196,11 @@ void partial_sum(const PartialSumArgs& a, hipStream_t stream) {
   if ((a.n & 3) || (a.stride & 3) || a.parts < 1) throw std::runtime_error("partial_sum: n and stride must be multiples of 4, parts >= 1");
   launch("partial_sum", partial_sum_kernel, dim3((unsigned)(((a.n >> 2) + 255) / 256), (unsigned)ceil_div(a.parts, kPartGroup)), dim3(256), 0,
          stream, a);
+}
+
+void part_reduce(const PartReduceArgs& a, int total_items, hipStream_t stream) {
+  if (!a.table || a.n_entries < 1 || total_items < 1 || !a.slots || (a.slot_stride & 3)) throw std::runtime_error("part_reduce: bad arguments");
+  launch("part_reduce", part_reduce_kernel, dim3(total_items), dim3(256), 0, stream, a);
 }
 
 void slot_reduce(const SlotReduceArgs& a, hipStream_t stream) {

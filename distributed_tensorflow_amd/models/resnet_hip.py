@@ -57,7 +57,7 @@ class ResNetHipStep(StepProgramBase):
 
     def __init__(self, n: int, batch: int, arena: Optional[ParamArena] = None, *, optimizer: str = "adam",
                  num_buckets: int = 1, num_classes: int = NUM_CLASSES, training: bool = True,
-                 device: str | torch.device = "cuda"):
+                 device: str | torch.device = "cuda", deterministic: Optional[bool] = None):
         nv.require()
         if optimizer not in ("adam", "momentum"):
             raise ValueError("optimizer must be 'adam' or 'momentum'")
@@ -157,6 +157,15 @@ class ResNetHipStep(StepProgramBase):
             # per-XCD copies of the filter gradients (see ConvWgradArgs::dw_slot_stride), summed into
             # the gradient arena at the end of every bucket segment
             self._wslots = torch.zeros(nv.STAT_SLOTS, arena.total, **f32)
+            # Deterministic gradients: every workgroup stores its part of a filter gradient into a copy
+            # of its own and one launch per bucket adds the copies in a fixed order (nv.GradientParts),
+            # instead of float atomics in arrival order. Default on; DTF_DETERMINISTIC=0 (or
+            # deterministic=False: replicas whose kernels short-circuit, which must find zeros, not
+            # last step's copies, behind a kernel that returned early) keeps the atomics.
+            if deterministic is None:
+                deterministic = os.environ.get("DTF_DETERMINISTIC", "1") != "0"
+            self.deterministic = bool(deterministic)
+            self._parts = nv.GradientParts(self._wslots) if self.deterministic else None
 
         self._record(num_buckets)
         self.set_hyper(lr_t=0.0)
@@ -190,7 +199,7 @@ class ResNetHipStep(StepProgramBase):
         a = self.arena
         off, spec = a.offsets[name], a.spec(name)
         dw = self._wslots[0, off:off + spec.numel].view(spec.shape)
-        nv.conv_wgrad(x, dout, dw, stride=stride, in_bn=in_bn, slot_stride=a.total)
+        nv.conv_wgrad(x, dout, dw, stride=stride, in_bn=in_bn, slot_stride=a.total, parts=self._parts)
 
     def _wpk(self, name: str, bwd: bool = False) -> torch.Tensor:
         off, n = (self._pk_bwd if bwd else self._pk_fwd)[name]
@@ -287,7 +296,7 @@ class ResNetHipStep(StepProgramBase):
                     kw["tile_counters"] = self._tile_ctr[self._tile_ctr_used:self._tile_ctr_used + nctr]
                     self._tile_ctr_used += nctr
                 return nv.conv_bwd_fused(dout, x, bn.fwd, self._wpk(conv.weight, True), dw_slot_view(conv.weight), bn.gsums,
-                                         slot_stride=a.total, extra=extra, out=out, **kw)
+                                         slot_stride=a.total, extra=extra, out=out, parts=self._parts, **kw)
             assert dout_bn is None and shortcut is None
             wgrad(x, dout, conv.weight, s, bn.fwd)
             _, pb, _ = same_pad(x.shape[1], 3, s)
@@ -298,6 +307,8 @@ class ResNetHipStep(StepProgramBase):
         def end_bucket(lo, hi_):
             if side:
                 p.sync_lanes(1, 0)
+            if self._parts is not None:
+                self._parts.reduce()
             nv.slot_reduce(a.grads, self._wslots, lo, hi_)
             self.bucket_ranges.append((lo, hi_))
             p.mark_segment()
@@ -382,7 +393,8 @@ class ResNetHipStep(StepProgramBase):
         if stem_fold and blocks[0].first_block:
             kw = dict(dy_bn=(self.c0, self.bn0.fwd, self.bn0.gsums), dy_dgamma=a.grad(self.bn0.gamma_name),
                       dy_dbeta=a.grad(self.bn0.beta_name))
-        nv.conv_stem_wgrad(self.images, self._d_c0, self._wslots[0, off0:off0 + 432].view(3, 3, 3, 16), slot_stride=a.total, **kw)
+        nv.conv_stem_wgrad(self.images, self._d_c0, self._wslots[0, off0:off0 + 432].view(3, 3, 3, 16), slot_stride=a.total,
+                           parts=self._parts, **kw)
         end_bucket(0, hi)
 
     def _record(self, num_buckets: int) -> None:

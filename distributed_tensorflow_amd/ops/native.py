@@ -11,6 +11,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Dict, Optional
 
+import numpy as np
 import torch
 
 from .reference import BN_EPSILON, same_pad
@@ -241,6 +242,53 @@ def conv_fprop(
     return out
 
 
+class GradientParts:
+    """Filter gradients without atomics. The filter-gradient kernels normally add each workgroup's
+    sum to one of STAT_SLOTS gradient copies with float atomics, in whatever order the workgroups
+    finish, so the last bits of a gradient differ from run to run. Handed one of these (`parts=`),
+    a kernel instead stores every workgroup's sum into a copy of its own, and `reduce()` - one launch
+    for all tensors registered since the last call - adds the copies up in a fixed order into the
+    slots (`slot_reduce` then adds the slots, also in a fixed order). Same state in, same bits out.
+    `slots` is the [STAT_SLOTS, n] buffer the gradients' `dw` views live in."""
+
+    ENTRY = np.dtype([("part", "<u8"), ("dst_off", "<i8"), ("copies", "<i4"), ("numel4", "<i4"), ("first_item", "<i4"), ("pad", "<i4")])
+
+    def __init__(self, slots: torch.Tensor):
+        if slots.dim() != 2 or slots.shape[0] != STAT_SLOTS or slots.dtype != torch.float32:
+            raise ValueError("GradientParts: slots must be float32 [STAT_SLOTS, n]")
+        self.slots = slots
+        self._pending = []
+        self._keep = []          # buffers and tables the recorded launches point into
+        self.bytes = 0
+
+    def add(self, dw: torch.Tensor, copies: int) -> int:
+        """Registers tensor `dw` (a view into slot 0) with `copies` workgroup copies; returns the
+        device address of the copies' buffer."""
+        numel = dw.numel()
+        if copies < 1 or numel % 4 or dw.storage_offset() % 4 or dw.untyped_storage().data_ptr() != self.slots.untyped_storage().data_ptr():
+            raise ValueError("GradientParts.add: dw must be a 16-byte aligned view into the slots")
+        buf = torch.empty(copies * numel, device=dw.device, dtype=torch.float32)
+        self._keep.append(buf)
+        self.bytes += buf.numel() * 4
+        self._pending.append((buf.data_ptr(), dw.storage_offset() - self.slots.storage_offset(), copies, numel // 4))
+        return buf.data_ptr()
+
+    def reduce(self) -> None:
+        if not self._pending:
+            return
+        require()
+        table = np.zeros(len(self._pending), dtype=self.ENTRY)
+        items = 0
+        for i, (ptr, off, copies, numel4) in enumerate(self._pending):
+            table[i] = (ptr, off, copies, numel4, items, 0)
+            items += (numel4 + 255) // 256 * STAT_SLOTS
+        assert self.ENTRY.itemsize == hip().PART_ENTRY_BYTES
+        t = torch.from_numpy(table.view(np.uint8).copy()).to(self.slots.device)
+        self._keep.append(t)
+        hip().part_reduce(t.data_ptr(), len(self._pending), items, self.slots.data_ptr(), self.slots.shape[1], stream())
+        self._pending = []
+
+
 def conv_wgrad(
     x: torch.Tensor,
     dout: torch.Tensor,
@@ -253,6 +301,7 @@ def conv_wgrad(
     co_tiles: int = 0,
     debug_skip: int = 0,
     dbg_stamps: Optional[torch.Tensor] = None,
+    parts: Optional[GradientParts] = None,
 ) -> torch.Tensor:
     """dw (HWIO, pre-zeroed or holding a running sum) += filter gradient.
 
@@ -282,6 +331,11 @@ def conv_wgrad(
         d["in_bn"] = in_bn.ref()
     if dbg_stamps is not None:
         d["dbg_stamps"] = _chk(dbg_stamps, "dbg_stamps", torch.int64)
+    if parts is not None:
+        # only the band kernel has the atomic-free flush; other shapes keep the atomics
+        copies = int(hip().conv_wgrad_band_copies(d, ks))
+        if copies > 0:
+            d["dw_part"] = parts.add(dw, copies)
     hip().conv_wgrad(d, ks, stream())
     return dw
 
@@ -307,7 +361,7 @@ def conv_stem_fwd(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] 
 
 
 def conv_stem_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, slot_stride: int = 0,
-                    dy_bn=None, dy_dgamma=None, dy_dbeta=None) -> None:
+                    dy_bn=None, dy_dgamma=None, dy_dbeta=None, parts: Optional[GradientParts] = None) -> None:
     """dw [3,3,3,16] += filter gradient of conv_stem_fwd (per-XCD copies with slot_stride).
     dy_bn = (y, BnState of y, backward sums): `dy` is the masked gradient at the output of the
     BatchNorm after the stem and that BatchNorm's backward is applied while dy is staged (as in
@@ -331,6 +385,8 @@ def conv_stem_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, slot_st
                 if t.numel() != 16:
                     raise ValueError(f"{key} must have 16 elements")
                 d[key] = _chk(t, key)
+    if parts is not None:
+        d["dw_part"] = parts.add(dw, int(hip().conv_stem_wgrad_copies(d)))
     hip().conv_stem_wgrad(d, stream())
 
 
@@ -461,7 +517,7 @@ def conv_bwd_fused_supported(x: torch.Tensor) -> bool:
 
 def conv_bwd_fused(dy, x, bn: BnState, wpk_t, dw, gsums, *, slot_stride: int = 0, extra=None, out=None,
                    dy_bn=None, dy_dgamma=None, dy_dbeta=None, dy_res=None, dy_out=None, dy_res_option_a=False,
-                   tile_counters=None):
+                   tile_counters=None, parts: Optional[GradientParts] = None):
     """Backward of y = conv3x3(relu(bn(x)), W), stride 1, in one kernel: returns the masked data
     gradient g, adds (sum g, sum g*xhat) to `gsums` and the filter gradient to `dw`
     (see csrc/kernels/conv.h: ConvBwdFusedArgs).
@@ -523,6 +579,8 @@ def conv_bwd_fused(dy, x, bn: BnState, wpk_t, dw, gsums, *, slot_stride: int = 0
         if tile_counters.dtype != torch.int32 or tile_counters.numel() < hip().BWD_TILE_COUNTERS:
             raise ValueError("tile_counters must be BWD_TILE_COUNTERS int32")
         d["tile_counters"] = _chk(tile_counters, "tile_counters", torch.int32)
+    if parts is not None:
+        d["dw_part"] = parts.add(dw, int(hip().conv_bwd_fused_copies(d)))
     hip().conv_bwd_fused(d, stream())
     return out
 

@@ -220,7 +220,10 @@ class HipReplica(ReplicaBase):
                 if model == "lenet":
                     self.step = LeNetHipStep(batch_size, self.arena, optimizer=optimizer, num_buckets=num_buckets)
                 else:
-                    self.step = ResNetHipStep(num_residual_blocks, batch_size, self.arena, optimizer=optimizer, num_buckets=num_buckets)
+                    # a step whose kernels can return early keeps the atomic gradient flush: behind a
+                    # short-circuited kernel the optimizer must find the zeros of the step prologue
+                    self.step = ResNetHipStep(num_residual_blocks, batch_size, self.arena, optimizer=optimizer, num_buckets=num_buckets,
+                                              deterministic=False if abortable else None)
         finally:
             if abortable:
                 nv.hip().set_abort_ref(0, 0)

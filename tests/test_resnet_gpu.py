@@ -1,4 +1,6 @@
 """Fused ResNet step on the GPU against the plain PyTorch autograd model of the same network."""
+import os
+
 import pytest
 import torch
 
@@ -243,23 +245,24 @@ print("ok")
 def test_queued_steps_keep_their_own_scalars():
     """Steps queued without any host synchronisation must each run with the learning rate and
     gradient scale staged for them (the host runs far ahead of the GPU in the benchmark loop):
-    same parameters, bit for bit, as a run that synchronises after every step. Only the optimizer
-    segment is replayed, on a fixed gradient: the forward/backward pass sums filter gradients with
-    float atomics and Adam amplifies their last-bit differences, which would drown the comparison."""
-    n, batch, steps = 1, 64, 48
+    same parameters, bit for bit, as a run that synchronises after every step. Whole steps -
+    forward, backward, optimizer - which is only a meaningful comparison because the step is
+    deterministic (per-workgroup gradient copies summed in a fixed order, statistics accumulated
+    exactly): Adam would amplify any last-bit difference between two runs."""
+    n, batch, steps = 1, 64, 24
 
     def run(sync_each, shift=0):
         step, _, _ = _make(n, batch)
+        assert step.deterministic
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
             step.instantiate(per_segment=True)
-            gen = torch.Generator(device="cuda").manual_seed(11)
-            step.arena.grads.copy_(torch.randn(step.arena.grads.shape, device="cuda", generator=gen))
             for t in range(1, steps + 1):
                 # values that differ a lot from step to step, so a mix-up is visible
                 k = t + shift
                 step.set_hyper(lr_t=ref.adam_lr_t(1e-3, t) * (1.0 + (k % 3)), grad_scale=1.0 / (1 + k % 4))
-                step.run(step.num_segments - 1, True)
+                for seg in range(step.num_segments):
+                    step.run(seg, True)
                 if sync_each:
                     s.synchronize()
         s.synchronize()
@@ -270,6 +273,48 @@ def test_queued_steps_keep_their_own_scalars():
     mixed = run(True, shift=1)
     assert not torch.equal(synced, mixed)        # the yardstick: scalars one step off are visible
     assert torch.equal(synced, queued)
+
+
+@pytest.mark.parametrize("n,batch,num_buckets", [(1, 64, 1), (1, 256, 3), (3, 128, 1)])
+def test_training_is_reproducible_bit_for_bit(n, batch, num_buckets):
+    """Two runs of 24 training steps from the same state end with identical parameters, optimizer
+    slots and loss-carrying gradients: no float atomics in arrival order anywhere in the step
+    (filter gradients: one copy per workgroup, added in a fixed order; statistics: exact fp64
+    accumulation on a grid; classifier gradients: fixed-order in-block sums)."""
+    def run():
+        step, _, _ = _make(n, batch, num_buckets=num_buckets)
+        assert step.deterministic
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            step.instantiate(per_segment=True)
+            for t in range(1, 25):
+                step.set_hyper(lr_t=ref.adam_lr_t(1e-3, t))
+                for seg in range(step.num_segments):
+                    step.run(seg, True)
+        s.synchronize()
+        return step.arena.params.clone(), step.arena.grads.clone(), step.arena.slots["m"].clone(), step.arena.slots["v"].clone()
+
+    a, b = run(), run()
+    for x, y, what in zip(a, b, ("parameters", "gradients", "m", "v")):
+        assert torch.equal(x, y), f"{what} differ: max |d| = {float((x - y).abs().max()):.3e}"
+
+
+def test_atomic_and_copy_gradient_flush_agree():
+    """DTF_DETERMINISTIC=0 keeps the float-atomic flush (what short-circuiting replicas run): same
+    gradients up to summation order."""
+    step_d, images, labels = _make(3, 64)
+    os.environ["DTF_DETERMINISTIC"] = "0"
+    try:
+        step_a, _, _ = _make(3, 64)
+    finally:
+        del os.environ["DTF_DETERMINISTIC"]
+    assert step_d.deterministic and not step_a.deterministic
+    for st in (step_d, step_a):
+        st.set_hyper(lr_t=0.0)
+        st.run(graph=False)
+    torch.cuda.synchronize()
+    for name in step_d.arena.names():
+        assert _rel(step_a.arena.grad(name), step_d.arena.grad(name)) < 2e-5, name
 
 
 def test_set_scalars_values_travel_with_the_launch():
