@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec of synchronous data-parallel ResNet CIFAR-10 training.
 
-  python bench.py --gpus N --steps K --warmup W [--model resnet20] [--batch 256]
+  python bench.py --gpus N --steps K --warmup W [--model resnet20|lenet|...] [--batch 256] [--input replay|gpu_batcher]
 
 N > 1 runs one rank per GPU over RCCL. Under torchrun RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
 come from the environment; started plainly as `python bench.py --gpus N` the script starts the N
@@ -33,7 +33,15 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 from distributed_tensorflow_amd import launch  # noqa: E402
 
-MODELS = {"resnet8": 1, "resnet20": 3, "resnet32": 5, "resnet56": 9, "resnet110": 18}
+MODELS = {"resnet8": 1, "resnet20": 3, "resnet32": 5, "resnet56": 9, "resnet110": 18, "lenet": 0}
+T_START = time.time()
+
+
+def mark(stage: str) -> None:
+    """Timestamped per-rank stage marker on stderr: when a multi-GPU run stops, the last marker of
+    every rank says which layer it stopped in (rendezvous, peer mapping, graph capture, first step,
+    first collective)."""
+    print("[bench rank %s +%.3fs] %s" % (os.environ.get("RANK", "0"), time.time() - T_START, stage), file=sys.stderr, flush=True)
 
 
 def cpu_floor(model: str):
@@ -219,6 +227,11 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--model", default="resnet20", choices=sorted(MODELS))
+    ap.add_argument("--input", choices=["replay", "gpu_batcher"], default="replay",
+                    help="replay: one device-resident batch is reused every step (the input pipeline is outside the timed "
+                         "region). gpu_batcher: every timed step draws a fresh batch from a synthetic data set resident in "
+                         "HBM through the training driver's own input path (ResNet: shuffled indices + random crop + "
+                         "per-image whitening in one kernel, data/cifar10.py GpuTrainBatcher; LeNet: data/mnist.py GpuBatcher)")
     ap.add_argument("--batch", type=int, default=1024,
                     help="per-GPU batch (weak scaling). 1024 is sized for the MI355X (activations + gradients of ResNet-20 "
                          "take ~1.5 GB of the 288 GB HBM and each layer launches >=2 workgroups per CU); the reference's "
@@ -258,8 +271,10 @@ def main() -> None:
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and not launch.launched_by_torchrun():
-        # The parent never touches the GPU: it only counts devices (which initialises nothing),
-        # starts one fresh process per rank and relays rank 0's JSON line.
+        # The parent never touches the GPU: it counts the devices in the kernel driver's sysfs tree
+        # (launch.visible_gpus: no HIP runtime in this process), starts one fresh process per rank
+        # and relays rank 0's JSON line. Every rank checks the count again from the inside
+        # (check_topology: distinct GPUs behind the ranks).
         ndev = launch.visible_gpus()
         if ndev < args.gpus and not args.share_gpu:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but {ndev} GPU(s) visible; pass --share-gpu --backend gloo to "
@@ -270,50 +285,94 @@ def main() -> None:
         code = launch.spawn_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, devices=ndev)
         raise SystemExit(code)
     if args.mode != "sync":
+        if args.model == "lenet" or args.input != "replay":
+            raise SystemExit("bench.py: the policy modes time ResNet steps on a replayed batch")
         return bench_policy(args)
 
-    from distributed_tensorflow_amd.models.resnet_hip import ResNetHipStep
     from distributed_tensorflow_amd.ops import reference as ref
     from distributed_tensorflow_amd.parallel.comm import Communicator
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; for the CPU floor run bench/cpu_reference.py")
+    mark("start: creating the process group" if args.gpus > 1 or args.rehearse_collectives else "start")
     comm = Communicator.from_env(backend=args.backend, force_group=args.rehearse_collectives)
     world = comm.world
     multi = world > 1 or args.rehearse_collectives
     topo = check_topology(args, comm)
+    if multi:
+        mark("process group up: %d rank(s), backend %s, %d distinct GPU(s)" % (world, topo["backend"], topo["distinct_gpus"]))
+    lenet = args.model == "lenet"
     n = MODELS[args.model]
     torch.manual_seed(1234 + comm.rank)
     if args.buckets <= 0:
+        from distributed_tensorflow_amd.models.lenet import lenet_param_specs
         from distributed_tensorflow_amd.models.resnet import resnet_param_specs
         from distributed_tensorflow_amd.parallel.comm import default_grad_buckets
 
-        args.buckets = default_grad_buckets(sum(sp.numel for sp in resnet_param_specs(n)))
+        args.buckets = default_grad_buckets(sum(sp.numel for sp in (lenet_param_specs() if lenet else resnet_param_specs(n))))
 
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        step = ResNetHipStep(n, args.batch, optimizer=args.optimizer, num_buckets=args.buckets if multi else 1)
+        if lenet:
+            from distributed_tensorflow_amd.models.lenet_hip import LeNetHipStep
+
+            step = LeNetHipStep(args.batch, optimizer=args.optimizer, num_buckets=args.buckets if multi else 1)
+        else:
+            from distributed_tensorflow_amd.models.resnet_hip import ResNetHipStep
+
+            step = ResNetHipStep(n, args.batch, optimizer=args.optimizer, num_buckets=args.buckets if multi else 1)
+        mark("step program recorded: %d kernels, %d segment(s)" % (step.kernel_count, step.num_segments))
         # identical initial parameters on every replica
         comm.broadcast(step.arena.params, 0)
+        if multi:
+            mark("parameters broadcast (first collective done)")
         if args.allreduce == "p2p":
             comm.enable_p2p(step.arena.grads_full.numel())
-        images = torch.randn(args.batch, 32, 32, 3, device=comm.device)
+            mark("peer handles imported (p2p all-reduce buffers mapped)")
+        hw, ch = (28, 1) if lenet else (32, 3)
+        images = torch.randn(args.batch, hw, hw, ch, device=comm.device)
         labels = torch.randint(0, 10, (args.batch,), device=comm.device)
         step.load_batch(images, labels)
+        batcher = None
+        if args.input == "gpu_batcher":
+            import numpy as np
+
+            rs = np.random.RandomState(99 + comm.rank)
+            if lenet:
+                from distributed_tensorflow_amd.data import mnist as mnist_data
+
+                # MNIST-shaped synthetic training set (60000 x 28 x 28 x 1 in [-0.5, 0.5], int64 labels), resident in HBM
+                ds = mnist_data.DataSet(rs.uniform(-0.5, 0.5, size=(60000, 28, 28, 1)).astype(np.float32),
+                                        rs.randint(0, 10, size=60000).astype(np.int64))
+                batcher = mnist_data.GpuBatcher(ds, comm.device)
+            else:
+                from distributed_tensorflow_amd.data import cifar10 as cifar_data
+
+                # CIFAR-shaped synthetic training set, zero-padded by 2 like prepare_train_data's (50000 x 36 x 36 x 3)
+                data = np.zeros((50000, 36, 36, 3), dtype=np.float32)
+                data[:, 2:34, 2:34, :] = rs.randint(0, 256, size=(50000, 32, 32, 3)).astype(np.float32)
+                batcher = cifar_data.GpuTrainBatcher(data, rs.randint(0, 10, size=50000), 2, 7 + comm.rank, comm.device)
+                del data
+            mark("synthetic data set resident in HBM")
         mode = "off" if args.no_graph else args.graph
-        graph = (mode == "on") or (mode == "auto" and not step.side_stream)
+        graph = (mode == "on") or (mode == "auto" and not getattr(step, "side_stream", False))
         if graph:
             step.instantiate(per_segment=multi)
+            mark("hipGraph instantiated")
         nseg = step.num_segments
         ranges = step.bucket_ranges
         grads = step.arena.grads
         t_global = 0
+        # events around the collectives of a step (N > 1): their share of the step says where a scaling loss comes from
+        coll_events = []
 
-        def one_step() -> None:
+        def one_step(timed: bool = False) -> None:
             nonlocal t_global
             t_global += 1
+            if batcher is not None:
+                batcher.next_batch_into(step.images, step.labels)
             step.set_hyper(lr_t=ref.adam_lr_t(args.lr, t_global) if args.optimizer == "adam" else args.lr,
-                           grad_scale=1.0 / world, momentum=0.9, weight_decay=2e-4)
+                           grad_scale=1.0 / world, momentum=0.9, weight_decay=2e-4, step=t_global if lenet else None)
             if not multi:
                 step.run(-1, graph)
                 return
@@ -323,22 +382,34 @@ def main() -> None:
                 if i < nseg - 2:
                     comm.all_reduce_async(grads[lo:hi])   # overlaps the rest of backward
                 else:
-                    comm.all_reduce_inline(grads[lo:hi])  # nothing left to overlap with: no stream hand-offs
+                    # nothing left to overlap with: issued on the compute stream, so two events bracket exactly
+                    # the part of the step that is exposed communication
+                    if timed:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(stream)
+                    comm.all_reduce_inline(grads[lo:hi])
+                    if timed:
+                        e1.record(stream)
+                        coll_events.append((e0, e1))
             comm.wait_all()
             step.run(nseg - 1, graph)
 
-        for _ in range(args.warmup):
+        for w in range(args.warmup):
             one_step()
+            if w == 0:
+                stream.synchronize()
+                mark("first step done" + (" (with its gradient all-reduce)" if multi else ""))
         stream.synchronize()
         comm.barrier()
         torch.cuda.synchronize()
+        mark("warm-up done, timing %d steps" % args.steps)
         # one event per step boundary (recorded on the step's stream, never waited on inside the
         # timed region) gives the per-step GPU times for the p50
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t0 = time.perf_counter()
         marks[0].record(stream)
         for i in range(args.steps):
-            one_step()
+            one_step(timed=True)
             marks[i + 1].record(stream)
         stream.synchronize()
         torch.cuda.synchronize()
@@ -347,6 +418,8 @@ def main() -> None:
         loss = step.loss_value()
         per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
         p50 = per_step[len(per_step) // 2] if per_step else float("nan")
+        coll_ms = sum(e0.elapsed_time(e1) for e0, e1 in coll_events) / max(1, args.steps)
+        mark("timed region done")
 
     t = torch.tensor([dt], device=comm.device, dtype=torch.float64)
     if multi:
@@ -359,7 +432,7 @@ def main() -> None:
         value = args.batch * world * args.steps / dt
         floor = cpu_floor(args.model)
         print(json.dumps({
-            "metric": "images/sec (node) ResNet CIFAR-10 sync-SGD",
+            "metric": "images/sec (node) LeNet MNIST sync-SGD" if lenet else "images/sec (node) ResNet CIFAR-10 sync-SGD",
             "value": round(value, 1),
             "unit": "images/sec",
             "n_gpus": topo["distinct_gpus"],
@@ -375,11 +448,14 @@ def main() -> None:
             "scaling": "weak",
             "vs_baseline": round(value / floor, 2) if floor else None,
             "dtype": "fp32",
-            "data": "synthetic CIFAR-10-shaped images, random-init weights",
+            "data": "synthetic %s-shaped images, random-init weights" % ("MNIST" if lenet else "CIFAR-10"),
+            "input": args.input,
             "config": {
                 "model": args.model, "global_batch": args.batch * world, "per_gpu_batch": args.batch,
-                "reference_worker_batch": 256, "seq_len": None, "image": "32x32x3", "optimizer": args.optimizer,
-                "parallelism": f"dp{world}", "hip_graph": graph,
+                "reference_worker_batch": 128 if lenet else 256, "seq_len": None, "image": "28x28x1" if lenet else "32x32x3",
+                "optimizer": args.optimizer, "parallelism": f"dp{world}", "hip_graph": graph,
+                "deterministic": bool(getattr(step, "deterministic", False)),
+                "exposed_allreduce_ms_per_step": round(coll_ms, 4) if multi else None,
                 "allreduce": ("p2p" if comm.p2p is not None else topo["backend"]) if multi else "none", "grad_buckets": len(ranges),
                 "kernels_per_step": step.kernel_count, "final_loss": round(loss, 4),
                 "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),

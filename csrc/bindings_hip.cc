@@ -11,6 +11,7 @@
 #include "comm/p2p_allreduce.h"
 #include "comm/update_log.h"
 #include "comm/async_shards.h"
+#include "comm/link_probe.h"
 #include "kernels/conv.h"
 #include "kernels/ops.h"
 #include "runtime/program.h"
@@ -380,6 +381,15 @@ PYBIND11_MODULE(_hip, m) {
     m.attr("UW_ERROR") = (int)UW_ERROR; m.attr("UW_APPLIED") = (int)UW_APPLIED; m.attr("UW_STATS") = (int)UW_STATS;
     m.attr("UW_HIST_TAG") = (int)UW_HIST_TAG; m.attr("UW_HIST_AUX") = (int)UW_HIST_AUX;
   }
+  m.def("link_probe", [](const py::dict& d, uint64_t stream) {
+    LinkProbeArgs a{};
+    P(own_ctl, unsigned long long); P(peer_ctl, unsigned long long); P(own_buf, float); P(peer_buf, float);
+    P(counter, unsigned long long); P(result, unsigned long long);
+    V(payload_floats); V(iters); V(cas_iters); V(role); V(timeout_ticks);
+    link_probe(a, as_stream(stream));
+  });
+  m.attr("LINK_PROBE_CTL_BYTES") = (uint64_t)kLinkProbeCtlBytes;
+  m.attr("LP_COUNTER") = (int)LP_COUNTER;
   m.def("ipc_alloc", [](uint64_t bytes, bool fine) { return (uint64_t)ipc_alloc(bytes, fine); });
   m.def("ipc_free", [](uint64_t p) { ipc_free(reinterpret_cast<void*>(p)); });
   m.def("ipc_export", [](uint64_t p) { return py::bytes(ipc_export(reinterpret_cast<void*>(p))); });

@@ -194,37 +194,27 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HeadBwdArgs a) {
   }
 }
 
-// FC parameter gradients dW[c][k] = sum_n feat[n][c] * dz[n][k], db[k] = sum_n dz[n][k]: a workgroup
-// owns 16 elements; thread (element, split) walks a sixteenth of the batch, the sixteen partial sums
-// of an element are added in split order and the result is stored - no atomics, so the gradient has
-// the same bits on every run.
-constexpr int kParamElems = 16, kParamSplits = 16;
+// FC parameter gradients dW[c][k] = sum_n feat[n][c] * dz[n][k], db[k] = sum_n dz[n][k]: one wave per
+// element; lane l walks samples l, l + 64, ... and the 64 partial sums are combined by a butterfly
+// of lane exchanges - a fixed tree - then stored. No atomics: the same bits on every run.
+constexpr int kParamElems = 4;   // waves (elements) per workgroup
 __global__ __launch_bounds__(256) void head_param_grad_kernel(HeadBwdArgs a) {
   DTF_ABORT_GUARD(a);
-  __shared__ float part[kParamSplits][kParamElems + 1];
-  const int el = threadIdx.x & (kParamElems - 1), sp = threadIdx.x / kParamElems;
-  const int e = blockIdx.x * kParamElems + el;
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * kParamElems + (threadIdx.x >> 6);
   const int C = a.C, K = a.K;
-  const int per = (a.B + kParamSplits - 1) / kParamSplits;
-  const int n0 = sp * per;
-  const int n1 = (n0 + per < a.B) ? n0 + per : a.B;
   float s = 0.f;
   if (e < C * K) {
     const int c = e / K, k = e - c * K;
-    for (int n = n0; n < n1; ++n) s += a.feat[(size_t)n * C + c] * a.dlogits[(size_t)n * K + k];
+    for (int n = lane; n < a.B; n += 64) s += a.feat[(size_t)n * C + c] * a.dlogits[(size_t)n * K + k];
   } else if (e < C * K + K) {
     const int k = e - C * K;
-    for (int n = n0; n < n1; ++n) s += a.dlogits[(size_t)n * K + k];
+    for (int n = lane; n < a.B; n += 64) s += a.dlogits[(size_t)n * K + k];
   }
-  part[sp][el] = s;
-  __syncthreads();
-  if (threadIdx.x < kParamElems) {
-    const int e2 = blockIdx.x * kParamElems + threadIdx.x;
-    float t = 0.f;
-#pragma unroll
-    for (int p = 0; p < kParamSplits; ++p) t += part[p][threadIdx.x];
-    if (e2 < C * K) a.d_fc_w[e2] += t;
-    else if (e2 < C * K + K) a.d_fc_b[e2 - C * K] += t;
+  s = wave_sum(s);
+  if (lane == 0) {
+    if (e < C * K) a.d_fc_w[e] += s;
+    else if (e < C * K + K) a.d_fc_b[e - C * K] += s;
   }
 }
 

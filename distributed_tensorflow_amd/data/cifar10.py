@@ -212,9 +212,9 @@ class GpuTrainBatcher:
             self._host = torch.zeros((b, 3), dtype=torch.int32).pin_memory()
         h = self._host.numpy()
         h[:, 0] = idx
-        for i in range(b):   # same draw order as random_crop_and_flip: row offset, then column offset
-            h[i, 1] = self.rng.randint(low=0, high=max(1, 2 * self.padding))
-            h[i, 2] = self.rng.randint(low=0, high=max(1, 2 * self.padding))
+        # same draw order as random_crop_and_flip, image by image: row offset, then column offset (one
+        # array draw yields the same stream as 2 b scalar draws, without 2 b interpreter round trips)
+        h[:, 1:3] = self.rng.randint(low=0, high=max(1, 2 * self.padding), size=(b, 2))
         dev = self._host.to(images_out.device, non_blocking=True)
         index = dev[:, 0].contiguous()
         offs = dev[:, 1:3].contiguous()

@@ -1,7 +1,8 @@
 """Self-launch of one rank per GPU on the local node.
 
 `python bench.py --gpus N` (and any other entry point that wants N local ranks without torchrun)
-calls `spawn_local_ranks` from a parent process that has NOT touched the GPU: the parent only
+calls `spawn_local_ranks` from a parent process that has NOT touched the GPU (it counts the devices
+in the kernel driver's sysfs tree, not through the HIP runtime): the parent only
 starts N fresh children of the same command line with the torchrun environment contract
 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and relays rank 0's standard output.
 It never replaces itself with another program, so a process that has initialised the GPU is never
@@ -32,14 +33,45 @@ def launched_by_torchrun(env: Optional[Dict[str, str]] = None) -> bool:
     return "RANK" in env and "WORLD_SIZE" in env
 
 
-def visible_gpus() -> int:
-    """Number of GPUs visible to this process, without initialising any of them."""
-    try:
-        import torch
+KFD_NODES = "/sys/class/kfd/kfd/topology/nodes"
 
-        return int(torch.cuda.device_count())
-    except Exception:  # noqa: BLE001 - no torch / no driver: nothing visible
+
+def _mask_count(value: str) -> int:
+    """Entries of a HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES style list (the list ends at the
+    first entry that is not a device: '-1' hides everything behind it)."""
+    n = 0
+    for item in value.split(","):
+        item = item.strip()
+        if not item or item.startswith("-"):
+            break
+        n += 1
+    return n
+
+
+def visible_gpus(env: Optional[Dict[str, str]] = None, kfd_nodes: str = KFD_NODES) -> int:
+    """Number of GPUs the rank processes will see, found WITHOUT loading the HIP runtime: the launcher
+    parent goes on to start children and must not have touched the GPU. The kernel driver lists its
+    compute nodes in sysfs (a node with `simd_count` > 0 is a GPU, the others are CPUs); the
+    visibility variables then cut that list down. Returns 0 when there is no amdgpu driver."""
+    env = os.environ if env is None else env
+    total = 0
+    try:
+        for node in os.listdir(kfd_nodes):
+            try:
+                with open(os.path.join(kfd_nodes, node, "properties")) as f:
+                    for line in f:
+                        key, _, val = line.partition(" ")
+                        if key == "simd_count":
+                            total += int(val) > 0
+                            break
+            except (OSError, ValueError):
+                continue
+    except OSError:
         return 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if var in env:
+            total = min(total, _mask_count(env[var]))
+    return total
 
 
 def rank_environment(rank: int, world: int, port: int, devices: int, base: Optional[Dict[str, str]] = None) -> Dict[str, str]:
@@ -99,6 +131,7 @@ def spawn_local_ranks(argv: Sequence[str], world: int, *, devices: Optional[int]
                     p.wait(timeout=10)
                 except subprocess.TimeoutExpired:
                     p.kill()
+                    p.wait()       # reaped: its exit status is known below
             break
         time.sleep(poll_s)
     t.join(timeout=5)

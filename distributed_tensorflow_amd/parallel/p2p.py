@@ -98,3 +98,64 @@ class P2PAllReduce:
             h.ipc_free(self._own_x)
             h.ipc_free(self._own_f)
             self._own_x = self._own_f = 0
+
+
+def link_probe(comm, payload_bytes: int = 1 << 20, iters: int = 200, cas_iters: int = 2000, timeout_s: float = 10.0) -> dict:
+    """First-contact probe between ranks 0 and 1 (csrc/comm/link_probe.hip): ping-pong of one flag
+    word, then of the flag plus `payload_bytes`, over IPC-mapped fine-grained HBM with the update
+    log's own primitives (release store / acquire load / compare-exchange at system scope), and a
+    compare-exchange counter both ranks increment. Every rank of `comm` must call it; ranks above 1
+    only take part in the collectives. Returns, on ranks 0 and 1:
+      flag_round_trip_us, payload_round_trip_us, payload_gb_s (both directions), bad_words, cas_lost,
+      cas_retries, timed_out."""
+    nv.require()
+    h = nv.hip()
+    ticks_per_s = P2PAllReduce.TICKS_PER_SECOND
+    floats = max(0, payload_bytes // 16 * 4)
+    own_ctl = h.ipc_alloc(int(h.LINK_PROBE_CTL_BYTES), True)
+    own_buf = h.ipc_alloc(max(16, floats * 4), True)
+    handles = comm.all_gather_object((h.ipc_export(own_ctl), h.ipc_export(own_buf)))
+    out: dict = {}
+    imported: List[int] = []
+    error = None
+    try:
+        if comm.rank < 2 and comm.world >= 2:
+            peer = 1 - comm.rank
+            peer_ctl, peer_buf = (h.ipc_import(x) for x in handles[peer])
+            imported += [peer_ctl, peer_buf]
+    except Exception as e:   # noqa: BLE001 - reported on every rank below
+        error = f"rank {comm.rank}: {e!r}"
+    errors = [e for e in comm.all_gather_object(error) if e]
+    if errors:
+        h.ipc_free(own_ctl)
+        h.ipc_free(own_buf)
+        raise RuntimeError("link probe: peer HBM cannot be mapped (" + "; ".join(errors) + ")")
+    comm.barrier()
+    if comm.rank < 2 and comm.world >= 2:
+        result = torch.zeros(8, dtype=torch.int64).pin_memory()
+        word = 16 * 8   # bytes between control words (one per 128-byte line)
+        counter = (own_ctl if comm.rank == 0 else peer_ctl) + int(h.LP_COUNTER) * word
+        h.link_probe(dict(own_ctl=own_ctl, peer_ctl=peer_ctl, own_buf=own_buf, peer_buf=peer_buf, counter=counter,
+                          payload_floats=floats, iters=iters, cas_iters=cas_iters, role=comm.rank,
+                          timeout_ticks=int(timeout_s * ticks_per_s), result=result.data_ptr()), nv.stream())
+        torch.cuda.synchronize()
+        r = result.numpy()
+        out = dict(flag_round_trip_us=float(r[0]) / ticks_per_s * 1e6 / iters,
+                   payload_round_trip_us=float(r[1]) / ticks_per_s * 1e6 / iters if floats else 0.0,
+                   payload_gb_s=(2.0 * floats * 4 * iters) / (float(r[1]) / ticks_per_s) / 1e9 if floats and r[1] else 0.0,
+                   bad_words=int(r[2]), timed_out=bool(r[3]), cas_retries=int(r[4]), payload_bytes=floats * 4, iters=iters)
+    comm.barrier()
+    if comm.rank == 0 and comm.world >= 2:
+        final = int(h.ulog_peek(own_ctl, int(h.LP_COUNTER), 1)[0])
+        out["cas_lost"] = 2 * cas_iters - final
+    lost = comm.all_gather_object(out.get("cas_lost"))[0]
+    if out:
+        out["cas_lost"] = lost
+    torch.cuda.synchronize()
+    comm.barrier()
+    for p in imported:
+        h.ipc_release(p)
+    comm.barrier()
+    h.ipc_free(own_ctl)
+    h.ipc_free(own_buf)
+    return out

@@ -93,6 +93,15 @@ class _CifarFeed:
             self.gpu_batcher.next_batch_into(st.images, st.labels)
 
 
+_T0 = time.time()
+
+
+def stage(rank: int, what: str) -> None:
+    """Timestamped bring-up marker (stderr, every rank): when a multi-GPU job stops during start-up,
+    the last marker of each rank names the layer it stopped in."""
+    log.info("STAGE worker=%d +%.3fs %s", rank, time.time() - _T0, what)
+
+
 def _inject_straggler(flags, rank: int, rng: random.Random) -> None:
     if flags.inject_straggler_ms <= 0 or not flags.inject_straggler_ranks:
         return
@@ -131,6 +140,7 @@ def train(flags, model: str) -> Dict:
     device = flags.device
     comm = Communicator.from_env(backend=flags.comm_backend or None, device="cpu" if device == "cpu" else None)
     world, rank = comm.world, comm.rank
+    stage(rank, "process group up: %d rank(s), backend %s" % (world, comm.topology().get("backend", "?") if hasattr(comm, "topology") else "?"))
     is_chief = rank == 0
     num_workers = world
     # Both must be > 0 in a distributed run (reference: distributed_train.py:120-122); the ps
@@ -216,6 +226,8 @@ def train(flags, model: str) -> Dict:
     )
     # On the GPU the dataset lives in HBM: ResNet crops + whitens with one kernel per step, LeNet
     # slices its batches device-to-device
+    stage(rank, "replica built (%s)" % ("step program recorded, hipGraph instantiated" if getattr(replica, "use_graph", False)
+                                        else "step program recorded" if hasattr(replica, "step") else "CPU"))
     gpu_feed = hasattr(replica, "step") and flags.gpu_data_pipeline
     if gpu_feed:
         feed.to_gpu(replica.device)
@@ -232,9 +244,12 @@ def train(flags, model: str) -> Dict:
         for t in replica.arena.slots.values():
             comm.broadcast(t, 0)
     replica.synchronize()
+    if world > 1:
+        stage(rank, "parameters broadcast (first collective done)")
 
     if flags.allreduce_impl == "p2p":
         comm.enable_p2p(replica.arena.grads_full.numel())
+        stage(rank, "peer handles imported (p2p all-reduce)")
     elif flags.allreduce_impl != "rccl":
         raise ValueError("--allreduce_impl must be rccl or p2p")
 
@@ -253,12 +268,14 @@ def train(flags, model: str) -> Dict:
             start_version=global_step,
         )
         board.set_global_step(global_step) if is_chief else None
+        stage(rank, "peer handles imported (asynchronous shards)")
         strategy = None
     else:
         strategy = make_strategy(flags, comm, board, num_replicas_to_aggregate)
         strategy.start_version = global_step
         if strategy.uses_update_log and world > 1 and board is not None:
             ulog = strategy._get_log(replica)
+            stage(rank, "update log ready (%s)" % type(ulog).__name__)
             # nobody offers a gradient for an update beyond the end of the run, so a worker that reads
             # the (lagging) counters late cannot push the global step past max_steps + 1
             ulog.max_version = flags.max_steps + 1
@@ -373,6 +390,9 @@ def train(flags, model: str) -> Dict:
             if board is not None and is_chief:
                 board.set_global_step(global_step)
         log.info("DONE RUNNING SESSION...")
+        if cur_iteration == 0:
+            replica.synchronize()
+            stage(rank, "first step done")
         if cdf:
             timeout_client.broadcast_worker_finished_computing_gradients(cur_iteration)
             if is_chief:

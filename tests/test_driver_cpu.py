@@ -182,13 +182,17 @@ def test_cdf_method_emits_elapsed_and_iteration_times(tmp_path):
     lc = LocalCluster(cfg, **kw)
     assert lc.wait(["master", "worker0"], timeout_s=280)
     out_master = os.path.join(lc.base_out_dir, "out_master")
-    elapsed = benchmark.extract_compute_times(out_master)
+    elapsed = benchmark.extract_compute_records(out_master)
     iters = benchmark.extract_iteration_times(out_master)
+    assert benchmark.extract_compute_times(out_master) == [e[0] for e in elapsed]
     assert elapsed and all(len(e) == 3 and e[2] > 10 for e in elapsed)
     assert {e[1] for e in elapsed} == {0, 1}               # both workers reported
     assert elapsed == sorted(elapsed, key=lambda x: x[0]) and len(iters) >= 30
     rep = benchmark.print_worker_sorted_times(out_master)
     assert rep["p99"] >= rep["p50"] > 0
+    # two workers: the nearest-rank 95th / 99th / 100th percentile of an iteration is its slower worker
+    assert rep["iter_p95_mean"] == rep["iter_p99_mean"] == rep["iter_p100_mean"] >= rep["mean"]
+    assert rep["iter_p100_med"] <= rep["max"]
     lc.shutdown()
 
 
@@ -205,7 +209,10 @@ def test_benchmark_parsers_on_reference_shaped_logs(tmp_path):
                  "INFO:dtf:Num examples: 10000  Precision @ 1: 0.912300 Loss: 0.301000 Time: 1.500000\n")
     assert benchmark.current_iteration(str(m)) == 2
     assert benchmark.extract_step_times_losses(str(m)) == ([1, 2], [2.302585, 2.1], [0.25, 0.125])
-    assert benchmark.extract_compute_times(str(m)) == [(0.1, 0, 11), (0.3, 1, 11)]
+    assert benchmark.extract_compute_records(str(m)) == [(0.1, 0, 11), (0.3, 1, 11)]
+    assert benchmark.extract_compute_times(str(m)) == [0.1, 0.3]
+    rep = benchmark.print_worker_sorted_times(str(m))
+    assert rep["iter_p95_mean"] == rep["iter_p95_med"] == 0.3 and rep["max"] == 0.3 and abs(rep["mean"] - 0.2) < 1e-12
     assert benchmark.extract_iteration_times(str(m)) == [0.5, 0.6]
     assert benchmark.extract_times_losses_precision(str(e)) == ([1.5], [0.301], [0.9123], [2])
     res = benchmark.collect_results({"run": str(tmp_path)})

@@ -4,6 +4,7 @@ for a topology other than the one asked for."""
 import json
 import os
 import subprocess
+import time
 import sys
 import textwrap
 import types
@@ -113,3 +114,47 @@ def test_bench_check_topology_rejects_a_world_that_differs_from_gpus():
     assert topo == {"backend": "gloo", "ranks": 2, "distinct_gpus": 1, "rccl_ranks": 0}
     args = types.SimpleNamespace(gpus=8, share_gpu=False)
     assert mod.check_topology(args, FakeComm(8, 8, "nccl"))["rccl_ranks"] == 8
+
+
+def test_visible_gpus_counts_sysfs_nodes_without_the_hip_runtime(tmp_path):
+    """The launcher parent counts GPUs in the kernel driver's topology tree (nodes with SIMDs; CPU
+    nodes have none) and applies the visibility variables; it never calls into HIP."""
+    from distributed_tensorflow_amd import launch
+
+    nodes = tmp_path / "nodes"
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024, 1024]):      # two CPU sockets, four GPUs
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nmem_banks_count 1\n")
+    assert launch.visible_gpus({}, str(nodes)) == 4
+    assert launch.visible_gpus({"HIP_VISIBLE_DEVICES": "0,2"}, str(nodes)) == 2
+    assert launch.visible_gpus({"ROCR_VISIBLE_DEVICES": "1,-1,3"}, str(nodes)) == 1      # the list ends at -1
+    assert launch.visible_gpus({"HIP_VISIBLE_DEVICES": ""}, str(nodes)) == 0
+    assert launch.visible_gpus({"HIP_VISIBLE_DEVICES": "0,1,2,3,4,5,6,7"}, str(nodes)) == 4
+    assert launch.visible_gpus({}, str(tmp_path / "missing")) == 0                        # no amdgpu driver
+    # and counting leaves torch's GPU runtime untouched in the parent
+    code = "import torch; from distributed_tensorflow_amd import launch; launch.visible_gpus(); print(torch.cuda.is_initialized())"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=120)
+    assert r.stdout.strip() == "False", (r.stdout, r.stderr)
+
+
+def test_spawn_local_ranks_reports_every_exit_status(tmp_path):
+    """A rank that ignores SIGTERM is killed AND reaped: the exit-code list never holds None."""
+    from distributed_tensorflow_amd import launch
+
+    script = tmp_path / "r.py"
+    script.write_text(
+        "import os, signal, sys, time\n"
+        "r = int(os.environ['RANK'])\n"
+        "if r == 0: sys.exit(7)\n"
+        "signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+        "time.sleep(600)\n")
+    import io
+    import contextlib
+
+    err = io.StringIO()
+    t0 = time.time()
+    with contextlib.redirect_stderr(err):
+        code = launch.spawn_local_ranks([sys.executable, str(script)], 2, devices=1)
+    assert code == 7 and time.time() - t0 < 60
+    assert "None" not in err.getvalue() and "exit codes by rank [7, -9]" in err.getvalue()

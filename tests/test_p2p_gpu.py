@@ -41,3 +41,24 @@ def test_p2p_allreduce_matches_weighted_sum(world, n):
     out = run_workers(_p2p_worker, world, f"dtf_p2p_{os.getpid()}", n, timeout=240)
     for errs in out:
         assert max(errs) < 1e-4, errs
+
+
+def _probe_worker(rank, world, board_name):
+    from distributed_tensorflow_amd.parallel.comm import Communicator
+    from distributed_tensorflow_amd.parallel.p2p import link_probe
+
+    os.environ["LOCAL_RANK"] = "0"
+    comm = Communicator.from_env(backend="gloo")
+    out = link_probe(comm, payload_bytes=1 << 20, iters=50, cas_iters=1000)
+    comm.close()
+    return out
+
+
+def test_link_probe_ping_pong_over_ipc_mapped_memory():
+    """Flag and 1 MB ping-pong plus a contended compare-exchange counter between two processes, here
+    through IPC mappings on one GPU (tests/test_zz_multi_gpu.py runs the same probe between two GPUs):
+    release / acquire hand-offs deliver the payload intact and no increment is lost."""
+    out = run_workers(_probe_worker, 2, f"dtf_probe_{os.getpid()}", timeout=240)
+    for o in out:
+        assert not o["timed_out"] and o["bad_words"] == 0 and o["cas_lost"] == 0, o
+        assert 0.5 < o["flag_round_trip_us"] < 500 and o["payload_gb_s"] > 0.5, o

@@ -123,9 +123,15 @@ def _last_list(fname: str, tag: str):
     return ast.literal_eval(found)
 
 
-def extract_compute_times(fname: str) -> List[Tuple[float, int, int]]:
-    """Last `ELAPSED TIMES [(time, worker, iteration), ...]` line of out_master."""
+def extract_compute_records(fname: str) -> List[Tuple[float, int, int]]:
+    """Last `ELAPSED TIMES [(time, worker, iteration), ...]` line of out_master, whole records."""
     return _last_list(fname, "ELAPSED TIMES ")
+
+
+def extract_compute_times(fname: str) -> List[float]:
+    """The compute times of that line alone, what the time-CDF plot draws
+    (reference: DistributedLeNet/tools/benchmark.py:113-122)."""
+    return [r[0] for r in extract_compute_records(fname)]
 
 
 def extract_iteration_times(fname: str) -> List[float]:
@@ -133,31 +139,52 @@ def extract_iteration_times(fname: str) -> List[float]:
 
 
 def print_worker_sorted_times(fname: str) -> Dict[str, float]:
-    """Percentile report of per-worker compute times (reference: benchmark.py:60-111)."""
-    elapsed = extract_compute_times(fname)
-    if not elapsed:
+    """Percentile report of the per-worker compute times of a worker-time CDF run, with the rows of
+    the reference's report (reference: DistributedLeNet/tools/benchmark.py:60-111): spread of all
+    times, then - per iteration, nearest-rank - the 95th / 99th / 100th percentile over the workers,
+    each summarised by its mean and its median across iterations. Returns the same numbers."""
+    print("File: %s" % fname)
+    print("-----------------------------")
+    records = extract_compute_records(fname)
+    if not records:
         print("no ELAPSED TIMES line in", fname)
         return {}
-    times = np.array([e[0] for e in elapsed])
-    out = {
-        "mean": float(times.mean()), "std": float(times.std()), "max": float(times.max()),
-        "p50": float(np.percentile(times, 50)), "p80": float(np.percentile(times, 80)),
-        "p90": float(np.percentile(times, 90)), "p95": float(np.percentile(times, 95)), "p99": float(np.percentile(times, 99)),
-    }
-    per_iter: Dict[int, List[float]] = {}
-    for t, _, it in elapsed:
-        per_iter.setdefault(it, []).append(t)
-    full = [v for v in per_iter.values() if len(v) > 1]
-    if full:
-        out["iter_p95_mean"] = float(np.mean([np.percentile(v, 95) for v in full]))
-        out["iter_p99_mean"] = float(np.mean([np.percentile(v, 99) for v in full]))
-        out["iter_max_mean"] = float(np.mean([np.max(v) for v in full]))
+    times = np.array([r[0] for r in records], dtype=np.float64)
+    by_iteration: Dict[int, List[float]] = {}
+    for t, _worker, it in records:
+        by_iteration.setdefault(it, []).append(t)
+
+    def nearest(values: List[float], q: float) -> float:
+        return float(np.percentile(values, q, method="nearest"))
+
+    p95 = [nearest(v, 95) for v in by_iteration.values()]
+    p99 = [nearest(v, 99) for v in by_iteration.values()]
+    p100 = [nearest(v, 100) for v in by_iteration.values()]
+    rows = [
+        ("Stdev: ", "std", float(times.std())),
+        ("Max: ", "max", float(times.max())),
+        ("80 Percentile:", "p80", float(np.percentile(times, 80))),
+        ("90 Percentile:", "p90", float(np.percentile(times, 90))),
+        ("95 Percentile:", "p95", float(np.percentile(times, 95))),
+        ("99 Percentile:", "p99", float(np.percentile(times, 99))),
+        ("Mean of 95 percentile (across iterations)", "iter_p95_mean", float(np.mean(p95))),
+        ("Med of 95 percentile (across iterations)", "iter_p95_med", float(np.median(p95))),
+        ("Mean of 99 percentile (across iterations)", "iter_p99_mean", float(np.mean(p99))),
+        ("Med of 99 percentile (across iterations)", "iter_p99_med", float(np.median(p99))),
+        ("Mean of 100 percentile (across iterations)", "iter_p100_mean", float(np.mean(p100))),
+        ("Med of 100 percentile (across iterations)", "iter_p100_med", float(np.median(p100))),
+        ("Mean:", "mean", float(times.mean())),
+    ]
+    out: Dict[str, float] = {}
+    for label, key, value in rows:
+        print(label, value)
+        out[key] = value
+    print(p99)
+    out["p50"] = float(np.percentile(times, 50))
     its = extract_iteration_times(fname)
     if its:
         out["iteration_time_mean"] = float(np.mean(its))
         out["iteration_time_p50"] = float(np.percentile(its, 50))
-    for k, v in out.items():
-        print("%s: %f" % (k, v))
     return out
 
 
@@ -208,7 +235,7 @@ def plot_time_cdfs(results: Dict[str, Dict], outdir: str) -> None:
     plt.figure()
     any_data = False
     for name, r in results.items():
-        ts = sorted(e[0] for e in r.get("compute_times", []))
+        ts = sorted(r.get("compute_times", []))
         if ts:
             any_data = True
             plt.plot(ts, np.arange(1, len(ts) + 1) / len(ts), label=name)

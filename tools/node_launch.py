@@ -90,12 +90,11 @@ def _alive(pid: int) -> bool:
 
 
 def _gpu_count() -> int:
-    try:
-        import torch
+    """GPUs on this node, counted in the kernel driver's sysfs tree: the launcher is the parent of
+    every rank process and never loads the HIP runtime itself."""
+    from distributed_tensorflow_amd.launch import visible_gpus
 
-        return torch.cuda.device_count()
-    except Exception:
-        return 0
+    return visible_gpus()
 
 
 class LocalCluster:
@@ -121,6 +120,15 @@ class LocalCluster:
             json.dump(st, f, indent=1)
 
     def topology(self) -> Dict:
+        """Roles started for this cfg. A cfg written for more replicas than this node runs (the
+        reference's sweeps use 50 EC2 workers, reference: DistributedLeNet/cfg/50_workers/*) is scaled:
+        `max_workers` (default: one replica per GPU) replicas, with the number of gradients per update
+        scaled by the same factor, so "40 of 50" becomes "6 of 8". The caps behind that: the device
+        update log addresses 8 replicas (one node's GPUs; csrc/comm/update_log.h: kUlogMaxPeers, a
+        16-bit contributor mask next to the update number and count in ONE 64-bit word that arrivals
+        compare-exchange), the host update log 16 (csrc/host/board.h: kAggMaxRanks, same word layout);
+        plain synchronous training has no such cap (the process group alone, any number of ranks).
+        Passing max_workers above the GPU count puts several replicas on a GPU (--comm_backend=gloo)."""
         n_rep = self.cfg.num_workers
         agg = self.cfg.replicas_to_aggregate
         cap = self.max_workers or (_gpu_count() or os.cpu_count() or 1)
