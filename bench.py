@@ -232,6 +232,11 @@ def main() -> None:
                          "region). gpu_batcher: every timed step draws a fresh batch from a synthetic data set resident in "
                          "HBM through the training driver's own input path (ResNet: shuffled indices + random crop + "
                          "per-image whitening in one kernel, data/cifar10.py GpuTrainBatcher; LeNet: data/mnist.py GpuBatcher)")
+    ap.add_argument("--matmul", choices=["fp32", "bf16x6"], default="fp32",
+                    help="fp32 (the headline): every product on the exact-fp32 matrix instruction. bf16x6: opt-in second line - the "
+                         "forward pass of the stride-1 ResNet layers on the bf16 matrix pipe, both operands split into three bf16 "
+                         "values, six partial products per product, fp32 accumulation (error against fp64 next to the exact "
+                         "path's: profiles/r3_split_error_table.txt)")
     ap.add_argument("--batch", type=int, default=1024,
                     help="per-GPU batch (weak scaling). 1024 is sized for the MI355X (activations + gradients of ResNet-20 "
                          "take ~1.5 GB of the 288 GB HBM and each layer launches >=2 workgroups per CU); the reference's "
@@ -320,7 +325,7 @@ def main() -> None:
         else:
             from distributed_tensorflow_amd.models.resnet_hip import ResNetHipStep
 
-            step = ResNetHipStep(n, args.batch, optimizer=args.optimizer, num_buckets=args.buckets if multi else 1)
+            step = ResNetHipStep(n, args.batch, optimizer=args.optimizer, num_buckets=args.buckets if multi else 1, matmul=args.matmul)
         mark("step program recorded: %d kernels, %d segment(s)" % (step.kernel_count, step.num_segments))
         # identical initial parameters on every replica
         comm.broadcast(step.arena.params, 0)
@@ -448,6 +453,8 @@ def main() -> None:
             "scaling": "weak",
             "vs_baseline": round(value / floor, 2) if floor else None,
             "dtype": "fp32",
+            "matmul": "fp32 (v_mfma_f32_16x16x4_f32)" if args.matmul == "fp32" or lenet else
+                      "bf16x6 split, fp32 accumulate (forward of the stride-1 layers; everything else fp32 MFMA)",
             "data": "synthetic %s-shaped images, random-init weights" % ("MNIST" if lenet else "CIFAR-10"),
             "input": args.input,
             "config": {

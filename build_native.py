@@ -86,6 +86,7 @@ def build_hip(force: bool = False, jobs: int = 8) -> Path:
     ]
     if os.environ.get("DTF_CONV_DEBUG") == "1":   # run-time ablation switches of the band kernels (bench/conv_ablation.py)
         common.append("-DDTF_CONV_DEBUG=1")
+    common += os.environ.get("DTF_EXTRA_DEFS", "").split()   # experiment switches, e.g. "-DDTF_FBAND_MTW4=1"
     srcs = sorted((CSRC / "kernels").glob("*.hip")) + sorted((CSRC / "comm").glob("*.hip")) + [
         CSRC / "runtime" / "program.cc", CSRC / "bindings_hip.cc",
     ]

@@ -76,6 +76,22 @@ PYBIND11_MODULE(_hip, m) {
     if (a.stride == 0) a.stride = 1;
     return conv_fprop(a, ks, as_stream(stream));
   });
+  m.def("conv_fprop_split", [](const py::dict& d, uint64_t stream) {
+    ConvFpropArgs a{};
+    P(in, const float); P(wpk, const float); P(out, float);
+    V(B); V(H); V(W); V(Cin); V(Ho); V(Wo); V(Cout); V(pad); V(stride); V(upsample);
+    V(in_mode); a.in_bn = as_bn(d, "in_bn");
+    V(res_mode); P(res, const float); a.res_bn = as_bn(d, "res_bn");
+    V(epi_mode); P(mask_src, const float); a.mask_bn = as_bn(d, "mask_bn");
+    P(extra, const float); P(out_sums, double);
+    if (a.stride == 0) a.stride = 1;
+    return conv_fprop_split(a, as_stream(stream));
+  });
+  m.def("pack_split_weights", [](uint64_t w, uint64_t out, int C, int flip, uint64_t stream) {
+    PackArgs a{reinterpret_cast<const float*>(w), reinterpret_cast<float*>(out), 3, C, C, flip};
+    pack_split_weights(a, as_stream(stream));
+  });
+  m.def("packed_split_floats", &packed_split_floats);
   m.def("pack_conv_weights", [](uint64_t w, uint64_t out, int ks, int Cin, int Cout, int flip, uint64_t stream) {
     PackArgs a{reinterpret_cast<const float*>(w), reinterpret_cast<float*>(out), ks, Cin, Cout, flip};
     pack_conv_weights(a, as_stream(stream));

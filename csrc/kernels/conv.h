@@ -78,6 +78,12 @@ struct PackArgs {
 };
 void pack_conv_weights(const PackArgs& a, hipStream_t stream);
 size_t packed_weight_floats(int ks, int Cin, int Cout, int transpose_flip);
+// Opt-in "bf16x6" variant of the stride-1 band kernel for the 16- and 32-channel layers (conv_fprop_split.hip):
+// fp32 operands cut exactly into three bf16 values each, six partial products per product on the bf16
+// matrix pipe, fp32 accumulation. `wpk` is then the output of pack_split_weights. 0 = not covered.
+size_t conv_fprop_split(const ConvFpropArgs& a, hipStream_t stream);
+void pack_split_weights(const PackArgs& a, hipStream_t stream);   // ks = 3, Cin == Cout in {16, 32}
+size_t packed_split_floats(int C);
 
 // Filter gradient: dW[kh,kw,ci,co] += sum_{n,y,x} act(in)[n, y*s+kh-pad, x*s+kw-pad, ci] * dout[n,y,x,co]
 // accumulated with fp32 atomics into `dw` (HWIO), which the caller zeroes beforehand. With

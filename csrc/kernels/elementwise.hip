@@ -1,6 +1,7 @@
 // Memory-bound kernels: elementwise, pooling, dropout, small reductions, augmentation, and
 // the one-launch filter re-packer. All stream 16 bytes per lane where the layout allows.
 #include "ops.h"
+#include "split_pack.h"
 #include "philox.h"
 
 namespace dtf {
@@ -330,6 +331,16 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(PackMultiArgs a) {
     below += __popcll(__ballot(hit));
   }
   const PackEntry t = a.table[below > 0 ? below - 1 : 0];
+  if (t.transpose_flip >= 2) {
+    // operand of the split-operand kernel (split_pack.h): two bf16 values per float slot
+    const int i2 = ((int)blockIdx.x - t.first_block) * 256 + threadIdx.x;
+    if (i2 >= t.n_floats) return;
+    const float* w2 = a.params + t.w_off;
+    const unsigned lo = split_packed_element(w2, t.Cin, t.transpose_flip - 2, 2 * i2);
+    const unsigned hi = split_packed_element(w2, t.Cin, t.transpose_flip - 2, 2 * i2 + 1);
+    reinterpret_cast<unsigned*>(a.packed + t.out_off)[i2] = lo | (hi << 16);
+    return;
+  }
   const int ks = t.ks;
   const int cin_e = t.transpose_flip ? t.Cout : t.Cin;
   const int cout_e = t.transpose_flip ? t.Cin : t.Cout;

@@ -271,7 +271,8 @@ struct CropWhitenArgs {
 void crop_whiten(const CropWhitenArgs& a, hipStream_t stream);
 
 // Packs every conv filter of a model in one launch. The table lives in device memory:
-// per entry {w_off, out_off, ks, Cin, Cout, transpose_flip, n_floats, first_block}.
+// per entry {w_off, out_off, ks, Cin, Cout, transpose_flip, n_floats, first_block}; transpose_flip 2 / 3 =
+// the split-operand layout of pack_split_weights (plain / data-gradient filter), n_floats = packed_split_floats.
 struct PackEntry { long long w_off; long long out_off; int ks, Cin, Cout, transpose_flip; int n_floats; int first_block; };
 struct PackMultiArgs { const float* params; float* packed; const PackEntry* table; int n_entries; };
 void pack_multi(const PackMultiArgs& a, int total_blocks, hipStream_t stream);

@@ -57,7 +57,7 @@ class ResNetHipStep(StepProgramBase):
 
     def __init__(self, n: int, batch: int, arena: Optional[ParamArena] = None, *, optimizer: str = "adam",
                  num_buckets: int = 1, num_classes: int = NUM_CLASSES, training: bool = True,
-                 device: str | torch.device = "cuda", deterministic: Optional[bool] = None):
+                 device: str | torch.device = "cuda", deterministic: Optional[bool] = None, matmul: Optional[str] = None):
         nv.require()
         if optimizer not in ("adam", "momentum"):
             raise ValueError("optimizer must be 'adam' or 'momentum'")
@@ -65,6 +65,13 @@ class ResNetHipStep(StepProgramBase):
         self.device = torch.device(device)
         self.training = training
         self.optimizer = optimizer
+        # "fp32": every convolution on the exact-fp32 matrix instruction (the default and the headline).
+        # "bf16x6": opt-in; the forward pass of the stride-1 layers runs on the bf16 matrix pipe with both
+        # operands split three ways and fp32 accumulation (csrc/kernels/conv_fprop_split.hip) - same
+        # results to within fp32 rounding, measured against fp64 in profiles/.
+        self.matmul = matmul or os.environ.get("DTF_MATMUL", "fp32")
+        if self.matmul not in ("fp32", "bf16x6"):
+            raise ValueError("matmul must be 'fp32' or 'bf16x6'")
         if arena is None:
             slots = ("m", "v") if optimizer == "adam" else ("m",)
             arena = ParamArena(resnet_param_specs(n, num_classes), self.device, slots if training else ())
@@ -111,11 +118,17 @@ class ResNetHipStep(StepProgramBase):
         off = 0
         self._pk_fwd: Dict[str, Tuple[int, int]] = {}
         self._pk_bwd: Dict[str, Tuple[int, int]] = {}
-        convs = [("conv0/conv", 3, 16)] + [(c.weight, c.cin, c.cout) for blk in self.blocks for c in (blk.conv1, blk.conv2)]
-        for name, cin, cout in convs:
-            nfl = nv.packed_floats(3, cin, cout, False)
+        convs = [("conv0/conv", 3, 16, 1)] + [(c.weight, c.cin, c.cout, c.stride) for blk in self.blocks for c in (blk.conv1, blk.conv2)]
+        self._split_fwd = set()     # layers whose forward pass runs on the split-operand kernel
+        for name, cin, cout, stride in convs:
+            if self.matmul == "bf16x6" and name != "conv0/conv" and nv.split_supported(cin, cout, stride):
+                nfl = int(nv.hip().packed_split_floats(cin))
+                self._split_fwd.add(name)
+                entries.append((a.offsets[name], off, 3, cin, cout, 2, nfl))
+            else:
+                nfl = nv.packed_floats(3, cin, cout, False)
+                entries.append((a.offsets[name], off, 3, cin, cout, 0, nfl))
             self._pk_fwd[name] = (off, nfl)
-            entries.append((a.offsets[name], off, 3, cin, cout, 0, nfl))
             off += nfl
             if training and name != "conv0/conv":
                 nfl = nv.packed_floats(3, cin, cout, True)
@@ -224,7 +237,7 @@ class ResNetHipStep(StepProgramBase):
             bn2 = self.bn2[k]
             nxt = self.bn1[k + 1] if k + 1 < len(self.blocks) else self.bnf
             nv.conv_fprop(x, self._wpk(blk.conv1.weight), ks=3, cout=blk.conv1.cout, stride=blk.conv1.stride,
-                          in_bn=bn1.fwd, out=self.c1[k], out_sums=bn2.fwd.sums)
+                          in_bn=bn1.fwd, out=self.c1[k], out_sums=bn2.fwd.sums, split=blk.conv1.weight in self._split_fwd)
             if blk.first_block:
                 res = dict(res_mode=nv.RES_BNRELU, res=x, res_bn=self.bn0.fwd)
             elif blk.increase_dim:
@@ -232,7 +245,7 @@ class ResNetHipStep(StepProgramBase):
             else:
                 res = dict(res_mode=nv.RES_IDENT, res=x)
             nv.conv_fprop(self.c1[k], self._wpk(blk.conv2.weight), ks=3, cout=blk.conv2.cout, in_bn=bn2.fwd,
-                          out=self.y[k], out_sums=nxt.fwd.sums, **res)
+                          out=self.y[k], out_sums=nxt.fwd.sums, split=blk.conv2.weight in self._split_fwd, **res)
             x = self.y[k]
         nv.head_fwd(x, self.bnf.fwd, a.param("fc/fc_weights"), a.param("fc/fc_bias"), self.labels, self.feat,
                     self.logits, self.dlogits, self.scalars, self._correct_buf)

@@ -140,6 +140,29 @@ def pack_weights(w: torch.Tensor, flip: bool = False, out: Optional[torch.Tensor
     return out
 
 
+def split_supported(cin: int, cout: int, stride: int = 1) -> bool:
+    """Shapes the bf16x6 kernel covers (see pack_split_weights)."""
+    return stride == 1 and cin == cout and cin in (16, 32, 64)
+
+
+def pack_split_weights(w: torch.Tensor, flip: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3 HWIO filter (C -> C channels, C = 16, 32 or 64) -> operand of the opt-in "bf16x6" kernel
+    (csrc/kernels/conv_fprop_split.hip): every fp32 value cut exactly into three bf16 values, in
+    MFMA fragment order. The tensor is float32-typed storage holding bf16 pairs. flip=True packs
+    the data-gradient filter."""
+    require()
+    ks, ks2, cin, cout = w.shape
+    if ks != 3 or ks2 != 3 or not split_supported(cin, cout):
+        raise ValueError("pack_split_weights: 3x3 filters with C -> C channels, C in 16, 32, 64")
+    n = int(hip().packed_split_floats(cin))
+    if out is None:
+        out = torch.empty(n, device=w.device, dtype=torch.float32)
+    if out.numel() != n:
+        raise ValueError("pack_split_weights: wrong output size")
+    hip().pack_split_weights(_chk(w, "w"), _chk(out, "out"), cin, int(flip), stream())
+    return out
+
+
 def conv_fprop(
     x: torch.Tensor,
     wpk: torch.Tensor,
@@ -163,8 +186,11 @@ def conv_fprop(
     out: Optional[torch.Tensor] = None,
     debug_skip: int = 0,
     dbg_stamps: Optional[torch.Tensor] = None,
+    split: bool = False,
 ) -> torch.Tensor:
-    """Forward-shaped convolution with fused prologue/epilogues (see csrc/kernels/conv.h)."""
+    """Forward-shaped convolution with fused prologue/epilogues (see csrc/kernels/conv.h).
+    split=True: `wpk` comes from pack_split_weights and the product runs on the bf16 matrix pipe with
+    three-way split operands (opt-in, stride-1 16- and 32-channel layers)."""
     require()
     b, h, w_, cin = x.shape
     if upsample:
@@ -189,7 +215,10 @@ def conv_fprop(
     cp = pad_cin(cin)
     kg = ks * ks * (cp // 16) if cp >= 16 else (ks * ks + 3) // 4
     nt_total = (cout + 15) // 16
-    if wpk.numel() != kg * nt_total * 256:
+    if split:
+        if ks != 3 or not split_supported(cin, cout, stride) or upsample or wpk.numel() != int(hip().packed_split_floats(cin)):
+            raise ValueError("conv_fprop(split=True): 3x3 stride-1 C -> C layers (C = 16, 32, 64) and a pack_split_weights filter")
+    elif wpk.numel() != kg * nt_total * 256:
         raise ValueError(f"packed filter has {wpk.numel()} floats, expected {kg * nt_total * 256}")
     if out is None:
         out = torch.empty((b, ho, wo, cout), device=x.device, dtype=torch.float32)
@@ -238,6 +267,10 @@ def conv_fprop(
         d["out_sums"] = _chk(out_sums, "out_sums", torch.float64)
     if dbg_stamps is not None:
         d["dbg_stamps"] = _chk(dbg_stamps, "dbg_stamps", torch.int64)
+    if split:
+        if not hip().conv_fprop_split(d, stream()):
+            raise ValueError("conv_fprop(split=True): this combination of shape and fused operations is not covered")
+        return out
     hip().conv_fprop(d, ks, stream())
     return out
 

@@ -58,12 +58,17 @@ BAND_SHAPES = [(32, 16, 16, 1), (16, 32, 32, 1), (8, 64, 64, 1), (32, 16, 32, 2)
 
 
 @pytest.mark.parametrize("b", [300, 1030])
+@pytest.mark.parametrize("split", [False, True], ids=["fp32", "bf16x6"])
 @pytest.mark.parametrize("res_mode", ["none", "ident", "bnrelu", "shortcut_a"])
 @pytest.mark.parametrize("shape", BAND_SHAPES)
-def test_band_forward_steady_state_against_fp64(shape, res_mode, b):
+def test_band_forward_steady_state_against_fp64(shape, res_mode, split, b):
+    """split: the opt-in split-operand kernel (bf16 matrix pipe, three-way split operands) under the
+    same oracle and the same tolerance as the exact-fp32 kernel."""
     hw, cin, cout, s = shape
     if s == 2 and res_mode != "none":
         pytest.skip("the stride-2 layers of the network are conv1 of a block: no residual epilogue")
+    if split and (s == 2 or (res_mode == "shortcut_a" and cin == 16)):
+        pytest.skip("the split-operand kernel covers the stride-1 layers (no option-A shortcut at 16 channels)")
     x = rnd(b, hw, hw, cin, scale=2.0, seed=3) + 0.3
     gamma, beta = rnd(cin, seed=4).abs() + 0.5, rnd(cin, scale=0.2, seed=5)
     wt = rnd(3, 3, cin, cout, scale=0.1, seed=6)
@@ -86,7 +91,8 @@ def test_band_forward_steady_state_against_fp64(shape, res_mode, b):
         want = want + ref.shortcut_a(src.double())
         kw = dict(res_mode=nv.RES_SHORTCUT_A, res=src)
     sums = nv.new_stats(cout, DEV)
-    got = nv.conv_fprop(x, nv.pack_weights(wt), ks=3, cout=cout, stride=s, in_bn=bn_state_for(x, gamma, beta), out_sums=sums, **kw)
+    wpk = nv.pack_split_weights(wt) if split else nv.pack_weights(wt)
+    got = nv.conv_fprop(x, wpk, ks=3, cout=cout, stride=s, in_bn=bn_state_for(x, gamma, beta), out_sums=sums, split=split, **kw)
     torch.cuda.synchronize()
     assert rel(got, want) < 2e-5, rel(got, want)
     flat = want.reshape(-1, cout)
@@ -124,13 +130,15 @@ def _reference_grads(loss_fn, state, images, labels, dtype):
     return loss.item(), {k: g.detach() for k, g in zip(params, grads)}
 
 
+@pytest.mark.parametrize("matmul", ["fp32", "bf16x6"])
 @pytest.mark.parametrize("batch", [512, 1024])
-def test_resnet20_step_at_benchmark_batch_matches_autograd(batch, unfold_convolutions):
+def test_resnet20_step_at_benchmark_batch_matches_autograd(batch, matmul, unfold_convolutions):
     from distributed_tensorflow_amd.models.resnet import resnet_loss
     from distributed_tensorflow_amd.models.resnet_hip import ResNetHipStep
 
     n = 3
-    step = ResNetHipStep(n, batch)
+    step = ResNetHipStep(n, batch, matmul=matmul)
+    assert len(step._split_fwd) == (16 if matmul == "bf16x6" else 0)
     g = torch.Generator().manual_seed(1234)
     for s in step.arena.specs:
         if s.name.endswith("gamma"):

@@ -78,6 +78,51 @@ def test_conv_fprop_bn_prologue_and_stats(case):
     close(tot[cout:], (flat * flat).sum(0), 1e-5)
 
 
+@pytest.mark.parametrize("case", [(3, 32, 32, 16), (3, 16, 16, 32), (5, 8, 8, 64)])
+def test_conv_fprop_split_operands_forward_and_data_gradient(case):
+    """Opt-in split-operand kernel (csrc/kernels/conv_fprop_split.hip): BatchNorm prologue, statistics and
+    every residual mode of the forward pass, and the data-gradient form (flipped filter, ReLU mask,
+    backward sums), each against the same reference and tolerance as the exact-fp32 kernel."""
+    b, h, w, c = case
+    x = rnd(b, h, w, c, scale=2.0) + 0.3
+    gamma, beta = rnd(c).abs() + 0.5, rnd(c, scale=0.2)
+    wt = rnd(3, 3, c, c, scale=0.1)
+    bn = bn_state_for(x, gamma, beta)
+    a = torch.relu(ref.batch_norm(x, gamma, beta))
+    base = ref.conv2d_same(a, wt, 1)
+    wsp = nv.pack_split_weights(wt)
+    sums = nv.new_stats(c, DEV)
+    close(nv.conv_fprop(x, wsp, ks=3, cout=c, in_bn=bn, out_sums=sums, split=True), base)
+    tot = nv.stats_total(sums)
+    flat = base.reshape(-1, c).double()
+    close(tot[:c], flat.sum(0), 1e-5)
+    close(tot[c:], (flat * flat).sum(0), 1e-5)
+    res = rnd(b, h, w, c, seed=7)
+    close(nv.conv_fprop(x, wsp, ks=3, cout=c, in_bn=bn, res_mode=nv.RES_IDENT, res=res, split=True), base + res)
+    g2, b2 = rnd(c, seed=8).abs() + 0.5, rnd(c, scale=0.3, seed=9)
+    want = base + torch.relu(ref.batch_norm(res, g2, b2))
+    close(nv.conv_fprop(x, wsp, ks=3, cout=c, in_bn=bn, res_mode=nv.RES_BNRELU, res=res, res_bn=bn_state_for(res, g2, b2), split=True), want)
+    if c > 16:
+        src = rnd(b, 2 * h, 2 * w, c // 2, seed=10)
+        close(nv.conv_fprop(x, wsp, ks=3, cout=c, in_bn=bn, res_mode=nv.RES_SHORTCUT_A, res=src, split=True), base + ref.shortcut_a(src))
+    # data gradient: g = 1[bn(xin) > 0] * (conv(dy, W') + extra), sums of g and g * xhat
+    dy = rnd(b, h, w, c, seed=11)
+    extra = rnd(b, h, w, c, seed=12)
+    xin = rnd(b, h, w, c, scale=1.5, seed=13)
+    xbn = bn_state_for(xin, g2, b2)
+    wflip = wt.flip(0, 1).permute(0, 1, 3, 2).contiguous()
+    pre = ref.batch_norm(xin, g2, b2)
+    want_g = (ref.conv2d_same(dy, wflip, 1) + extra) * (pre > 0)
+    gs_split, gs_exact = nv.new_stats(c, DEV), nv.new_stats(c, DEV)
+    got = nv.conv_fprop(dy, nv.pack_split_weights(wt, flip=True), ks=3, cout=c, epi_mode=nv.EPI_MASK, mask_src=xin, mask_bn=xbn,
+                        extra=extra, out_sums=gs_split, split=True)
+    exact = nv.conv_fprop(dy, nv.pack_weights(wt, flip=True), ks=3, cout=c, epi_mode=nv.EPI_MASK, mask_src=xin, mask_bn=xbn,
+                          extra=extra, out_sums=gs_exact)
+    close(exact, want_g)
+    close(got, want_g)
+    close(nv.stats_total(gs_split), nv.stats_total(gs_exact), 1e-5)
+
+
 def test_conv_fprop_residual_modes():
     b, h, w, c = 4, 16, 16, 32
     x = rnd(b, h, w, c)

@@ -11,10 +11,10 @@ from distributed_tensorflow_amd.runtime.arena import ParamArena
 pytestmark = pytest.mark.gpu
 
 
-def _make(n, batch, optimizer="adam", num_buckets=1):
+def _make(n, batch, optimizer="adam", num_buckets=1, matmul=None):
     from distributed_tensorflow_amd.models.resnet_hip import ResNetHipStep
 
-    step = ResNetHipStep(n, batch, optimizer=optimizer, num_buckets=num_buckets)
+    step = ResNetHipStep(n, batch, optimizer=optimizer, num_buckets=num_buckets, matmul=matmul)
     g = torch.Generator().manual_seed(1234)
     # non-trivial BN affine parameters so their gradients are exercised
     for s in step.arena.specs:
@@ -40,9 +40,10 @@ def _rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
 
+@pytest.mark.parametrize("matmul", ["fp32", "bf16x6"])
 @pytest.mark.parametrize("n,num_buckets", [(1, 1), (3, 3)])
-def test_fused_step_matches_autograd(n, num_buckets):
-    step, images, labels = _make(n, 8, num_buckets=num_buckets)
+def test_fused_step_matches_autograd(n, num_buckets, matmul):
+    step, images, labels = _make(n, 8, num_buckets=num_buckets, matmul=matmul)
     step.set_hyper(lr_t=0.0)
     step.run(graph=False)
     torch.cuda.synchronize()
