@@ -13,4 +13,4 @@ run --model lenet --batch 256
 run --model lenet --batch 128
 run --model lenet --batch 1024 --input gpu_batcher
 run --model lenet --batch 128 --input gpu_batcher
-python tools/bench_brief.py < $out
+python tools/bench_brief.py $out

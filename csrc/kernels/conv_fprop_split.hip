@@ -40,43 +40,45 @@ typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 
 #define DTF_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
-// LDS cycles of the activation ds_read_b128 (4 = conflict free) for a per-pixel stride of `slots`
-// 16-byte slots: lane (q, p) reads slot (pixel(p) * slots + its channel slot) mod 16, pixel(p) being
-// pixel p of a 16-pixel tile inside the halo tile (rows of tw pixels, lw apart).
-constexpr int split_read_cycles(int slots, int cp, int tw, int lw) {
+// LDS cycles of one activation ds_read_b128 (4 = conflict free), worst case over the K steps and pixel
+// tiles of a band, for a plane laid out as [row][pixel] with `slots` 16-byte slots per pixel and `row_slots`
+// per row. Lane (q, p) of K step ks reads pixel p of a 16-pixel tile, shifted by the step's tap, at the
+// channel slot of its lane group; the hardware serves the lanes in the four groups below and serialises
+// lanes of a group whose slots are equal mod 16.
+constexpr int split_read_cycles(int cp, int tw, int slots, int row_slots) {
   constexpr int kGroup[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
                                  {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
-  int total = 0;
-  for (int half = 0; half < 2; ++half)
-    for (int g = 0; g < 2; ++g) {
-      int off[16] = {};
-      for (int k = 0; k < 16; ++k) {
-        const int lane = kGroup[g][k] + 32 * half;
-        const int q = lane >> 4, p = lane & 15;
-        const int pix = (p / tw) * lw + p % tw;
-        // 16 channels: lane groups 2-3 read the next tap, in the common case the next pixel of the row
-        off[k] = cp == 16 ? (pix + (q >> 1)) * slots + (q & 1) : pix * slots + q;
-      }
-      int worst = 1;
-      for (int k = 0; k < 16; ++k) {
-        int n = 1;
-        for (int j = 0; j < k; ++j) {
-          bool dup = false;
-          for (int i = 0; i < j; ++i) dup = dup || off[i] == off[j];
-          if (!dup && off[j] != off[k] && (off[j] & 15) == (off[k] & 15)) ++n;
+  const int ksteps = (9 * cp + 31) / 32;
+  int worst_total = 0;
+  for (int ks = 0; ks < ksteps; ++ks)
+    for (int mt = 0; mt < 2; ++mt) {
+      int total = 0;
+      for (int half = 0; half < 2; ++half)
+        for (int g = 0; g < 2; ++g) {
+          int slot[16] = {};
+          for (int k = 0; k < 16; ++k) {
+            const int lane = kGroup[g][k] + 32 * half;
+            const int q = lane >> 4, p = mt * 16 + (lane & 15);
+            int tap = ks, ch = q;
+            if (cp == 16) { tap = 2 * ks + (q >> 1); tap = tap > 8 ? 8 : tap; ch = q & 1; }
+            if (cp == 64) { tap = ks >> 1; ch = 4 * (ks & 1) + q; }
+            slot[k] = (p / tw + tap / 3) * row_slots + (p % tw + tap % 3) * slots + ch;
+          }
+          int worst = 1;
+          for (int k = 0; k < 16; ++k) {
+            int n = 1;   // distinct addresses before k on k's bank group
+            for (int j = 0; j < k; ++j) {
+              bool dup = slot[j] == slot[k];
+              for (int i = 0; i < j; ++i) dup = dup || slot[i] == slot[j];
+              if (!dup && (slot[j] & 15) == (slot[k] & 15)) ++n;
+            }
+            worst = n > worst ? n : worst;
+          }
+          total += worst;
         }
-        worst = n > worst ? n : worst;
-      }
-      total += worst;
+      worst_total = total > worst_total ? total : worst_total;
     }
-  return total;
-}
-constexpr int split_best_slots(int cp, int tw, int lw) {
-  const int base = cp / 8;   // 16-byte slots of a pixel's channels
-  int best = base + 1, cyc = split_read_cycles(base + 1, cp, tw, lw);
-  for (int s = base + 2; s <= base + 4; ++s)
-    if (split_read_cycles(s, cp, tw, lw) < cyc) { best = s; cyc = split_read_cycles(s, cp, tw, lw); }
-  return best;
+  return worst_total;
 }
 
 template <int CP, int TW, int TH>
@@ -86,9 +88,14 @@ struct FSplit {
   static constexpr bool STREAM = CP == 64;           // filter fragments streamed from L2 instead of held in registers
   static constexpr int C4 = CP / 4;
   static constexpr int LH = TH + 2, LW = TW + 2;
-  static constexpr int SLOTS = split_best_slots(CP, TW, LW);
+  // 16-byte slots per pixel and per row of a plane: the smallest conflict-free layouts (a search over
+  // 0-4 slots of pixel padding and 0-15 of row padding with split_read_cycles)
+  static constexpr int SLOTS = CP == 16 ? 2 : (CP == 32 ? 6 : 10);
+  static constexpr int ROW_SLOTS = LW * SLOTS + (CP == 64 ? 12 : 0);
+  static_assert(split_read_cycles(CP, TW, SLOTS, ROW_SLOTS) == 4, "activation reads must be conflict free");
   static constexpr int PSB = SLOTS * 16;             // bytes per pixel and plane
-  static constexpr int PLANE = LH * LW * PSB;        // bytes per plane (h, m, l)
+  static constexpr int ROWB = ROW_SLOTS * 16;        // bytes per row and plane
+  static constexpr int PLANE = LH * ROWB;            // bytes per plane (h, m, l)
   static constexpr int IN_CHUNKS = LH * TW * C4;     // only the image columns are staged
   static constexpr int NPF = (IN_CHUNKS + 255) / 256;
   static constexpr int N_MT = TH * TW / 16;
@@ -115,11 +122,11 @@ template <int CP, int TW, int TH, bool BWD>
 __global__ __launch_bounds__(256, 2) void conv_fprop_split_kernel(ConvFpropArgs a) {
   DTF_ABORT_GUARD(a);
   using G = FSplit<CP, TW, TH>;
-  constexpr int NT = G::NT, KS = G::KS, C4 = G::C4, LW = G::LW, PSB = G::PSB, PLANE = G::PLANE, P = G::P;
+  constexpr int NT = G::NT, KS = G::KS, C4 = G::C4, LW = G::LW, PSB = G::PSB, ROWB = G::ROWB, PLANE = G::PLANE, P = G::P;
   constexpr bool STREAM = G::STREAM;
   constexpr int WDEPTH = 3;          // K steps a streamed filter fragment is requested ahead of its use
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-  unsigned char* s_act = smem_b;                                        // [3][LH*LW][PSB]
+  unsigned char* s_act = smem_b;                                        // [3][LH][ROWB], pixels PSB apart
   uintx4* s_wl = reinterpret_cast<uintx4*>(smem_b + 3 * PLANE);         // [KS][NT][64]
   float* s_bn = reinterpret_cast<float*>(smem_b + 3 * PLANE + G::WL_UNITS * 16);   // in-BN scale[CP], shift[CP]
   float* s_stat = s_bn + 2 * CP;                                        // [2][NT*16] (block_stat_flush scratch lives in s_act)
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_split_kernel(ConvFpropArgs 
     const int r = (i / C4) / TW;
     const int c = (i / C4) % TW + 1;
     in_goff[k] = (r * a.W + (c - 1)) * CP + c4 * 4;
-    in_loff[k] = (r * LW + c) * PSB + c4 * 8;
+    in_loff[k] = r * ROWB + c * PSB + c4 * 8;
     in_row[k] = i < G::IN_CHUNKS ? r : -100000;
   }
   // B-operand byte offset inside a plane = pixel-tile base (per lane, poff below) + channel slot of the
@@ -203,10 +210,10 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_split_kernel(ConvFpropArgs 
   // filter row), or the same tap again (the padding step).
   const int q_slot = 16 * (CP == 16 ? (q & 1) : q);
   const int d1 = (CP == 16 && q >= 2) ? PSB : 0;
-  const int dx = (CP == 16 && q >= 2) ? (LW - 2) * PSB : 0;
+  const int dx = (CP == 16 && q >= 2) ? ROWB - 2 * PSB : 0;
   auto kconst = [](int ks) constexpr -> int {
     const int tap = CP == 64 ? ks >> 1 : (CP == 32 ? ks : 2 * ks);
-    return ((tap / 3) * LW + (tap % 3)) * PSB + (CP == 64 ? 64 * (ks & 1) : 0);
+    return (tap / 3) * ROWB + (tap % 3) * PSB + (CP == 64 ? 64 * (ks & 1) : 0);
   };
   auto kvar = [&](int ks) -> int { return CP != 16 ? 0 : (ks == 1 ? dx : (ks == 4 ? 0 : d1)); };
   const int lane_o = l15 * CP + ct * 16 + 4 * q;
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_split_kernel(ConvFpropArgs 
   }
   for (int i = tid; i < 3 * G::LH * 2 * (PSB / 4); i += 256) {
     const int w = i % (PSB / 4), side = (i / (PSB / 4)) & 1, r = (i / (2 * (PSB / 4))) % G::LH, plane = i / (2 * (PSB / 4) * G::LH);
-    reinterpret_cast<unsigned*>(s_act + plane * PLANE + (r * LW + (side ? LW - 1 : 0)) * PSB)[w] = 0u;
+    reinterpret_cast<unsigned*>(s_act + plane * PLANE + r * ROWB + (side ? LW - 1 : 0) * PSB)[w] = 0u;
   }
   __syncthreads();
 
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_split_kernel(ConvFpropArgs 
 #pragma unroll
   for (int i = 0; i < P; ++i) {
     const int p = (mg * P + i) * 16 + l15;
-    poff[i] = ((p / TW) * LW + (p % TW)) * PSB + q_slot;
+    poff[i] = (p / TW) * ROWB + (p % TW) * PSB + q_slot;
   }
 
   for (; t < total_tiles; t += gpz) {
