@@ -115,7 +115,8 @@ PYBIND11_MODULE(_hip, m) {
     P(dy_x, const float); a.dy_bn = as_bn(d, "dy_bn"); P(dy_gsums, const double); P(dy_dgamma, float); P(dy_dbeta, float);
     P(dy_res, const float); P(dy_out, float); V(dy_res_mode);
     P(tile_counters, int);
-    return conv_bwd_fused(a, as_stream(stream));
+    const bool split = d.contains("split") && d["split"].cast<bool>();   // wpk_t holds the split-operand packing
+    return split ? conv_bwd_split(a, as_stream(stream)) : conv_bwd_fused(a, as_stream(stream));
   });
   m.def("conv_bwd_fused_copies", [](const py::dict& d) {
     ConvBwdFusedArgs a{};
@@ -123,7 +124,8 @@ PYBIND11_MODULE(_hip, m) {
     a.bn = as_bn(d, "bn"); V(B); V(H); V(W); V(C);
     P(dy_x, const float); a.dy_bn = as_bn(d, "dy_bn"); P(dy_gsums, const double);
     P(dy_res, const float); P(dy_out, float); V(dy_res_mode);
-    return conv_bwd_fused_copies(a);
+    const bool split = d.contains("split") && d["split"].cast<bool>();
+    return split ? conv_bwd_split_copies(a) : conv_bwd_fused_copies(a);
   });
   m.def("conv_wgrad_band_copies", [](const py::dict& d, int ks) {
     ConvWgradArgs a{};
@@ -142,6 +144,7 @@ PYBIND11_MODULE(_hip, m) {
   });
   m.attr("PART_ENTRY_BYTES") = (int)sizeof(PartEntry);
   m.def("conv_bwd_fused_supported", &conv_bwd_fused_supported);
+  m.def("conv_bwd_split_supported", &conv_bwd_split_supported);
   m.def("conv_stem_fwd", [](const py::dict& d, uint64_t stream) {
     ConvStemArgs a{};
     P(x, const float); P(w, const float); P(y, float); P(sums, double); V(B);

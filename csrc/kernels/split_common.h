@@ -1,0 +1,93 @@
+// Pieces shared by the split-operand ("bf16x6") convolution kernels: vector types, the bf16 MFMA, the
+// three-way split of an fp32 value, and the layout of the staged activation planes with its bank model.
+#pragma once
+#include "common.h"
+#include "split_pack.h"
+
+namespace dtf {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+#define DTF_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// LDS cycles of one activation ds_read_b128 (4 = conflict free), worst case over the K steps and pixel
+// tiles of a band, for a plane laid out as [row][pixel] with `slots` 16-byte slots per pixel and `row_slots`
+// per row. Lane (q, p) of K step ks reads pixel p of a 16-pixel tile, shifted by the step's tap, at the
+// channel slot of its lane group; the hardware serves the lanes in the four groups below and serialises
+// lanes of a group whose slots are equal mod 16.
+constexpr int split_read_cycles(int cp, int tw, int slots, int row_slots) {
+  constexpr int kGroup[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                 {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+  const int ksteps = (9 * cp + 31) / 32;
+  int worst_total = 0;
+  for (int ks = 0; ks < ksteps; ++ks)
+    for (int mt = 0; mt < 2; ++mt) {
+      int total = 0;
+      for (int half = 0; half < 2; ++half)
+        for (int g = 0; g < 2; ++g) {
+          int slot[16] = {};
+          for (int k = 0; k < 16; ++k) {
+            const int lane = kGroup[g][k] + 32 * half;
+            const int q = lane >> 4, p = mt * 16 + (lane & 15);
+            int tap = ks, ch = q;
+            if (cp == 16) { tap = 2 * ks + (q >> 1); tap = tap > 8 ? 8 : tap; ch = q & 1; }
+            if (cp == 64) { tap = ks >> 1; ch = 4 * (ks & 1) + q; }
+            slot[k] = (p / tw + tap / 3) * row_slots + (p % tw + tap % 3) * slots + ch;
+          }
+          int worst = 1;
+          for (int k = 0; k < 16; ++k) {
+            int n = 1;   // distinct addresses before k on k's bank group
+            for (int j = 0; j < k; ++j) {
+              bool dup = slot[j] == slot[k];
+              for (int i = 0; i < j; ++i) dup = dup || slot[i] == slot[j];
+              if (!dup && (slot[j] & 15) == (slot[k] & 15)) ++n;
+            }
+            worst = n > worst ? n : worst;
+          }
+          total += worst;
+        }
+      worst_total = total > worst_total ? total : worst_total;
+    }
+  return worst_total;
+}
+
+// Three planes (h, m, l parts) of a band with a one-pixel halo: [row][pixel] with PSB bytes per pixel
+// (CP bf16 channels + padding) and ROWB per row.
+template <int CP, int TW, int TH>
+struct SplitPlanes {
+  static constexpr int LH = TH + 2, LW = TW + 2;
+  // 16-byte slots per pixel and per row of a plane: the smallest conflict-free layouts (a search over
+  // 0-4 slots of pixel padding and 0-15 of row padding with split_read_cycles)
+  static constexpr int SLOTS = CP == 16 ? 2 : (CP == 32 ? 6 : 10);
+  static constexpr int ROW_SLOTS = LW * SLOTS + (CP == 64 ? 12 : 0);
+  static_assert(split_read_cycles(CP, TW, SLOTS, ROW_SLOTS) == 4, "activation reads must be conflict free");
+  static constexpr int PSB = SLOTS * 16;             // bytes per pixel and plane
+  static constexpr int ROWB = ROW_SLOTS * 16;        // bytes per row and plane
+  static constexpr int PLANE = LH * ROWB;            // bytes per plane
+};
+
+// {bf16(x0), bf16(x1)} in one dword, round to nearest even (one instruction on gfx950)
+__device__ __forceinline__ unsigned bf16_pair(float x0, float x1) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x0), "v"(x1));
+  return r;
+}
+__device__ __forceinline__ float pair_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float pair_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+
+// Three-way split of four values, each part rounded to nearest: h = bf16(v), m = bf16(v - h),
+// l = bf16(v - h - m); the subtractions are exact, what is left after l is below 2^-26 |v|.
+__device__ __forceinline__ void split3(const floatx4& v, uintx2& h, uintx2& m, uintx2& l) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const float x0 = v[2 * e], x1 = v[2 * e + 1];
+    h[e] = bf16_pair(x0, x1);
+    const float r0 = x0 - pair_lo(h[e]), r1 = x1 - pair_hi(h[e]);
+    m[e] = bf16_pair(r0, r1);
+    l[e] = bf16_pair(r0 - pair_lo(m[e]), r1 - pair_hi(m[e]));
+  }
+}
+
+}  // namespace dtf

@@ -550,7 +550,7 @@ def conv_bwd_fused_supported(x: torch.Tensor) -> bool:
 
 def conv_bwd_fused(dy, x, bn: BnState, wpk_t, dw, gsums, *, slot_stride: int = 0, extra=None, out=None,
                    dy_bn=None, dy_dgamma=None, dy_dbeta=None, dy_res=None, dy_out=None, dy_res_option_a=False,
-                   tile_counters=None, parts: Optional[GradientParts] = None):
+                   tile_counters=None, parts: Optional[GradientParts] = None, split: bool = False):
     """Backward of y = conv3x3(relu(bn(x)), W), stride 1, in one kernel: returns the masked data
     gradient g, adds (sum g, sum g*xhat) to `gsums` and the filter gradient to `dw`
     (see csrc/kernels/conv.h: ConvBwdFusedArgs).
@@ -561,12 +561,21 @@ def conv_bwd_fused(dy, x, bn: BnState, wpk_t, dw, gsums, *, slot_stride: int = 0
     With dy_res / dy_out (and dy_bn) the gradient of an identity shortcut is added to that
     BatchNorm input gradient and the sum is written to dy_out (a buffer other than dy); with
     dy_res_option_a the shortcut is the resolution-halving one (2x2 average pool + channel padding)
-    and dy_res is the [B, H/2, W/2, 2C] gradient at its output."""
+    and dy_res is the [B, H/2, W/2, 2C] gradient at its output.
+
+    split=True: both products run on the bf16 matrix pipe with operands split three ways and fp32
+    accumulation (csrc/kernels/conv_bwd_split.hip); wpk_t is then pack_split_weights(w, flip=True)."""
     require()
     b, h, w_, c = x.shape
     if tuple(dy.shape) != (b, h, w_, c) or tuple(dw.shape) != (3, 3, c, c) or bn.channels != c:
         raise ValueError("conv_bwd_fused: shape mismatch")
-    if wpk_t.numel() != 9 * (c // 16) * (c // 16) * 256 or gsums.numel() != STAT_SLOTS * 2 * c:
+    if split:
+        if not hip().conv_bwd_split_supported(b, h, w_, c) or tile_counters is not None:
+            raise ValueError("conv_bwd_fused: the split-operand kernel does not cover this call")
+        want_w = int(hip().packed_split_floats(c))
+    else:
+        want_w = 9 * (c // 16) * (c // 16) * 256
+    if wpk_t.numel() != want_w or gsums.numel() != STAT_SLOTS * 2 * c:
         raise ValueError("conv_bwd_fused: packed filter / statistics block have the wrong size")
     if slot_stride:
         last = (dw.storage_offset() + (STAT_SLOTS - 1) * slot_stride + dw.numel()) * 4
@@ -612,6 +621,8 @@ def conv_bwd_fused(dy, x, bn: BnState, wpk_t, dw, gsums, *, slot_stride: int = 0
         if tile_counters.dtype != torch.int32 or tile_counters.numel() < hip().BWD_TILE_COUNTERS:
             raise ValueError("tile_counters must be BWD_TILE_COUNTERS int32")
         d["tile_counters"] = _chk(tile_counters, "tile_counters", torch.int32)
+    if split:
+        d["split"] = True
     if parts is not None:
         d["dw_part"] = parts.add(dw, int(hip().conv_bwd_fused_copies(d)))
     hip().conv_bwd_fused(d, stream())

@@ -344,9 +344,20 @@ def test_conv_pingpong_masked_dgrad(shape, with_extra):
     close(gt[c:], (want * xhat).reshape(-1, c).double().sum(0), 1e-4)
 
 
+def _bwd_filter(w, split, c):
+    """Data-gradient packing of w for the exact-fp32 kernel or its split-operand (bf16x6) twin."""
+    if not split:
+        return nv.pack_weights(w.detach(), flip=True)
+    if not nv.hip().conv_bwd_split_supported(1, 8, 8, c) and not nv.hip().conv_bwd_split_supported(1, 16, 16, c) \
+            and not nv.hip().conv_bwd_split_supported(1, 32, 32, c):
+        pytest.skip("no split-operand backward kernel for this channel count")
+    return nv.pack_split_weights(w.detach(), flip=True)
+
+
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("shape", [(5, 32, 16), (7, 16, 32), (9, 8, 64), (70, 8, 64), (300, 32, 16), (700, 16, 32)])
 @pytest.mark.parametrize("with_extra", [False, True])
-def test_conv_bwd_fused(shape, with_extra):
+def test_conv_bwd_fused(shape, with_extra, split):
     # one kernel: masked data gradient + BatchNorm-backward sums + filter gradient (per-XCD copies)
     b, h, c = shape
     x_pre = rnd(b, h, h, c, scale=1.5) + 0.1
@@ -363,9 +374,9 @@ def test_conv_bwd_fused(shape, with_extra):
     gs = nv.new_stats(c, DEV)
     assert nv.conv_bwd_fused_supported(x_pre)
     # dynamic band scheduling on the larger case, static striding otherwise
-    ctr = torch.zeros(nv.hip().BWD_TILE_COUNTERS, device=DEV, dtype=torch.int32) if b > 32 else None
-    got = nv.conv_bwd_fused(dy, x_pre, bn_state_for(x_pre, gamma, beta), nv.pack_weights(wt.detach(), flip=True),
-                            slots[0, :n].view(3, 3, c, c), gs, slot_stride=n + 64, extra=extra, tile_counters=ctr)
+    ctr = torch.zeros(nv.hip().BWD_TILE_COUNTERS, device=DEV, dtype=torch.int32) if b > 32 and not split else None
+    got = nv.conv_bwd_fused(dy, x_pre, bn_state_for(x_pre, gamma, beta), _bwd_filter(wt, split, c),
+                            slots[0, :n].view(3, 3, c, c), gs, slot_stride=n + 64, extra=extra, tile_counters=ctr, split=split)
     close(got, want)
     assert slots[:, n:].abs().max().item() == 0
     close(slots[:, :n].sum(0).view(dw_want.shape), dw_want)
@@ -376,8 +387,9 @@ def test_conv_bwd_fused(shape, with_extra):
     close(gt[c:], (want * xhat).reshape(-1, c).double().sum(0), 1e-4)
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("shape", [(5, 32, 16), (6, 16, 32), (9, 8, 64)])
-def test_conv_bwd_fused_with_bn_backward_prologue(shape):
+def test_conv_bwd_fused_with_bn_backward_prologue(shape, split):
     # x -> bn1/relu -> conv1 -> y -> bn2/relu -> conv2 -> z. The backward of conv1 takes the masked
     # gradient at bn2's output and applies bn2's backward while staging it.
     b, h, c = shape
@@ -404,8 +416,8 @@ def test_conv_bwd_fused_with_bn_backward_prologue(shape):
     slots = torch.zeros(nv.STAT_SLOTS, n, device=DEV)
     gs1 = nv.new_stats(c, DEV)
     dgam, dbet = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
-    got = nv.conv_bwd_fused(du2.contiguous(), x, bn_state_for(x, g1, b1), nv.pack_weights(w1.detach(), flip=True),
-                            slots[0].view(3, 3, c, c), gs1, slot_stride=n,
+    got = nv.conv_bwd_fused(du2.contiguous(), x, bn_state_for(x, g1, b1), _bwd_filter(w1, split, c),
+                            slots[0].view(3, 3, c, c), gs1, slot_stride=n, split=split,
                             dy_bn=(yd, bn_state_for(yd, g2.detach(), b2.detach()), gs2), dy_dgamma=dgam, dy_dbeta=dbet)
     close(got, want_g, 2e-4)
     close(slots.sum(0).view(dw1.shape), dw1, 2e-4)
@@ -413,9 +425,10 @@ def test_conv_bwd_fused_with_bn_backward_prologue(shape):
     close(dbet, db2, 1e-4)
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("option_a", [False, True])
 @pytest.mark.parametrize("shape", [(5, 32, 16), (6, 16, 32), (9, 8, 64), (300, 32, 16), (260, 16, 32)])
-def test_conv_bwd_fused_prologue_with_shortcut_gradient(shape, option_a):
+def test_conv_bwd_fused_prologue_with_shortcut_gradient(shape, option_a, split):
     # as above, and y also feeds an identity shortcut whose gradient `res` arrives from the block
     # after: the kernel stages dy = bn2_backward(du2) + res and writes it out as the block input gradient
     b, h, c = shape
@@ -454,8 +467,8 @@ def test_conv_bwd_fused_prologue_with_shortcut_gradient(shape, option_a):
     gs1 = nv.new_stats(c, DEV)
     dgam, dbet = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
     dy_out = torch.full_like(yd, 7.0)
-    got = nv.conv_bwd_fused(du2.contiguous(), x, bn_state_for(x, g1, b1), nv.pack_weights(w1.detach(), flip=True),
-                            slots[0].view(3, 3, c, c), gs1, slot_stride=n,
+    got = nv.conv_bwd_fused(du2.contiguous(), x, bn_state_for(x, g1, b1), _bwd_filter(w1, split, c),
+                            slots[0].view(3, 3, c, c), gs1, slot_stride=n, split=split,
                             dy_bn=(yd, bn_state_for(yd, g2.detach(), b2.detach()), gs2), dy_dgamma=dgam, dy_dbeta=dbet,
                             dy_res=res, dy_out=dy_out, dy_res_option_a=option_a)
     close(dy_out, dy_total, 2e-4)
