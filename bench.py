@@ -234,8 +234,8 @@ def main() -> None:
                          "per-image whitening in one kernel, data/cifar10.py GpuTrainBatcher; LeNet: data/mnist.py GpuBatcher)")
     ap.add_argument("--matmul", choices=["fp32", "bf16x6"], default="fp32",
                     help="fp32 (the headline): every product on the exact-fp32 matrix instruction. bf16x6: opt-in second line - the "
-                         "forward pass of the stride-1 ResNet layers on the bf16 matrix pipe, both operands split into three bf16 "
-                         "values, six partial products per product, fp32 accumulation (error against fp64 next to the exact "
+                         "stride-1 ResNet layers (forward, and the fused backward kernels of the 16- and 32-channel stages) on the bf16 "
+                         "matrix pipe, both operands split into three bf16 values, six partial products per product, fp32 accumulation (error against fp64 next to the exact "
                          "path's: profiles/r3_split_error_table.txt)")
     ap.add_argument("--batch", type=int, default=1024,
                     help="per-GPU batch (weak scaling). 1024 is sized for the MI355X (activations + gradients of ResNet-20 "
@@ -454,7 +454,7 @@ def main() -> None:
             "vs_baseline": round(value / floor, 2) if floor else None,
             "dtype": "fp32",
             "matmul": "fp32 (v_mfma_f32_16x16x4_f32)" if args.matmul == "fp32" or lenet else
-                      "bf16x6 split, fp32 accumulate (forward of the stride-1 layers; everything else fp32 MFMA)",
+                      "bf16x6 split, fp32 accumulate (stride-1 layers: %d forward and %d fused backward kernels; everything else fp32 MFMA)" % (len(step._split_fwd), len(step._split_bwd)),
             "data": "synthetic %s-shaped images, random-init weights" % ("MNIST" if lenet else "CIFAR-10"),
             "input": args.input,
             "config": {

@@ -48,8 +48,19 @@ for hw, c in shapes:
             slots = torch.zeros(nv.STAT_SLOTS, n, device="cuda")
             gs = nv.new_stats(c, "cuda")
             out = torch.empty_like(x)
-            for name, split in (("fp32", False), ("bf16x6", True)):
-                wpk = nv.pack_split_weights(wt, flip=True) if split else nv.pack_weights(wt, flip=True)
-                t = timeit(lambda: nv.conv_bwd_fused(dy, x, bn, wpk, slots[0, :n].view(3, 3, c, c), gs, slot_stride=n, out=out, split=split))
-                line += f" | {name} {t:.1f} us"
+            y = T.rnd(b, hw, hw, c, seed=8)
+            ybn = T.bn_state_for(y, gamma, beta)
+            ygs = nv.stats_from_totals(torch.cat([dy.reshape(-1, c).double().sum(0), (dy * y).reshape(-1, c).double().sum(0)]))
+            res, dy_out = T.rnd(b, hw, hw, c, seed=9), torch.empty_like(x)
+            res_a = T.rnd(b, hw // 2, hw // 2, 2 * c, seed=10) if c < 64 else None
+            variants = [("plain", {}), ("bn", dict(dy_bn=(y, ybn, ygs))), ("bn+res", dict(dy_bn=(y, ybn, ygs), dy_res=res, dy_out=dy_out))]
+            if res_a is not None:
+                variants.append(("bn+resA", dict(dy_bn=(y, ybn, ygs), dy_res=res_a, dy_out=dy_out, dy_res_option_a=True)))
+            for vname, kw in variants:
+                line += f" | {vname}:"
+                for name, split in (("fp32", False), ("bf16x6", True)):
+                    wpk = nv.pack_split_weights(wt, flip=True) if split else nv.pack_weights(wt, flip=True)
+                    t = timeit(lambda: nv.conv_bwd_fused(dy, x, bn, wpk, slots[0, :n].view(3, 3, c, c), gs, slot_stride=n, out=out, split=split, **kw))
+                    line += f" {name} {t:.1f}"
+            line += " us"
         print(line, flush=True)

@@ -53,20 +53,21 @@ struct BSplit {
   static constexpr int NPF_D = (D_CHUNKS + 255) / 256;
   static constexpr int NPF_X = (X_CHUNKS + 255) / 256;
   static constexpr int N_MT = TH * TW / 16;
-  static constexpr int P = N_MT / 4;                    // pixel tiles per wave (data gradient)
+  static constexpr int PD = N_MT / 2;                   // pixel tiles per data-gradient wave (waves 0-1)
+  static constexpr int PG = 2;                          // of which a group of two shares each filter fragment read
   static constexpr int WL_UNITS = KS * 64;              // 16-byte units of the l part of the block's filter slice
   static constexpr int NWL = (WL_UNITS + 255) / 256;
-  // filter gradient: output-channel tiles over the waves, the rest of the waves split the pixels
-  static constexpr int WP = CO_T >= 4 ? 4 : CO_T;
-  static constexpr int WX = 4 / WP;
+  // filter gradient (waves 2-3): one output-channel tile each, or one tile and half of the pixels each
+  static constexpr int WP = CO_T;
+  static constexpr int WX = 2 / WP;
   static constexpr int WSTEPS = TH * TW / 32;           // K = 32 steps of a band
   static constexpr int RED_STRIDE = C + 4;
   static constexpr int RED_BYTES = WX * 9 * 16 * RED_STRIDE * 4;
   static constexpr int TILE_BYTES = 3 * PL::PLANE + 3 * XPLANE;
   static constexpr int BUF_BYTES = TILE_BYTES > RED_BYTES ? TILE_BYTES : RED_BYTES;
   static constexpr int LDS_BYTES = BUF_BYTES + WL_UNITS * 16 + (6 * 16 + 3 * C) * 4;
-  static_assert(CO_T == WP, "one output-channel tile per wave");
-  static_assert(P % 2 == 0 && WSTEPS % WX == 0, "band must split evenly");
+  static_assert(CO_T == 1 || CO_T == 2, "one output-channel tile per filter-gradient wave");
+  static_assert(PD % PG == 0 && WSTEPS % WX == 0, "band must split evenly");
   static_assert(TW == 16 || TW == 32, "a K step of the filter gradient is one or two whole rows");
   static_assert(256 % (C / 4) == 0, "a thread's chunks share their channel group");
   static_assert(PL::PLANE < 65536, "LDS offsets must fit 16 bits");
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_split_kernel(ConvBwdFusedArgs
   using G = BSplit<C, TW, TH>;
   using PL = typename G::PL;
   constexpr int KS = G::KS, CO_T = G::CO_T, LW = G::LW, PSB = PL::PSB, ROWB = PL::ROWB, PLANE = PL::PLANE;
-  constexpr int XPB = G::XPB, XPLANE = G::XPLANE, P = G::P, WP = G::WP, WX = G::WX;
+  constexpr int XPB = G::XPB, XPLANE = G::XPLANE, WX = G::WX;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   unsigned char* s_dy = smem_b;                                          // [3][LH][ROWB], pixels PSB apart
   unsigned char* s_x = smem_b + 3 * PLANE;                               // [3][TH*TW][XPB]
@@ -121,14 +122,8 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_split_kernel(ConvBwdFusedArgs
     dg2 = stat_total(a.dy_gsums, C + tid, C);
     dgam = a.dy_bn.gamma[tid];
   }
-  // filter slice of the data gradient, [K step][channel tile][h, m, l][lane] x 16 bytes: h and m parts in registers
+  // filter slice of the data gradient, [K step][channel tile][h, m, l][lane] x 16 bytes; its l part goes to LDS
   const uintx4* wsrc = reinterpret_cast<const uintx4*>(a.wpk_t);
-  uintx4 wh[KS], wm[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    wh[ks] = wsrc[((ks * CO_T + z) * 3 + 0) * 64 + lane];
-    wm[ks] = wsrc[((ks * CO_T + z) * 3 + 1) * 64 + lane];
-  }
   uintx4 wl_reg[G::NWL];
 #pragma unroll
   for (int k = 0; k < G::NWL; ++k) {
@@ -163,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_split_kernel(ConvBwdFusedArgs
   const int r_goff0 = (((d_r0 - 1) >> 1) * (TW / 2) + (d_ix >> 1)) * (2 * C) + C / 2 + d_c4 * 4;
   auto r_goff = [&](int k) -> int { return r_goff0 + k * (RPK / 2) * (TW / 2) * (2 * C); };
   unsigned okbits = 0;
-  auto load_band = [&](int t) {
+  auto load_band = [&](int t) __attribute__((always_inline)) {
     const int n = t / bands;
     const int oy0 = (t - n * bands) * TH;
     const long long doff = ((long long)(n * a.H + oy0 - 1) * a.W) * C;
@@ -188,9 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_split_kernel(ConvBwdFusedArgs
       pf_x[k] = *reinterpret_cast<const floatx4*>(x0 + x_goff0 + k * XPK * C);
     }
   };
-  // The shortcut term of the next band is requested between the two MFMA phases: by then the data
-  // gradient's registers are free, and the filter-gradient phase covers the latency.
-  auto load_res = [&](int t) {
+  auto load_res = [&](int t) __attribute__((always_inline)) {
     const int n = t / bands;
     const int oy0 = (t - n * bands) * TH;
     const float* r0 = RES == 2 ? a.dy_res + ((long long)(n * (a.H / 2) + oy0 / 2) * (TW / 2)) * (2 * C)
@@ -199,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_split_kernel(ConvBwdFusedArgs
     for (int k = 0; k < G::NPF_D; ++k)
       if ((okbits >> k) & 1u) pf_r[k] = *reinterpret_cast<const floatx4*>(r0 + (RES == 2 ? r_goff(k) : d_goff(k)));
   };
-  auto write_band = [&](long long doff) {
+  auto write_band = [&](long long doff) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < G::NPF_D; ++k)
       if (d_ok(k)) {
@@ -290,7 +283,14 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_split_kernel(ConvBwdFusedArgs
   }
   __syncthreads();
 
-  // ---- per-lane constants --------------------------------------------------------------------------
+  // ---- wave roles and per-lane constants ----------------------------------------------------------------
+  // Waves 0-1 compute the data gradient of the whole band, waves 2-3 its filter gradient, at the same
+  // time: a data-gradient wave keeps the filter fragments in registers and no filter-gradient
+  // accumulators, a filter-gradient wave the other way round, so both fit the register file next to
+  // the next band's prefetch (a wave doing both phases in turn spills the prefetched values, which
+  // makes the loads synchronous). The MFMA counts of the two roles are equal (32 channels) or 10 : 9.
+  const bool dgrad_wave = wave < 2;
+  const int rw = wave & 1;                   // index within the role
   // data gradient: B-operand byte offsets as in conv_fprop_split.hip (channel slot of the lane group +
   // the K step's tap shift; with 16 channels lane groups 2-3 read the tap after that of groups 0-1)
   const int q_slot = 16 * (C == 16 ? (q & 1) : q);
@@ -302,103 +302,123 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_split_kernel(ConvBwdFusedArgs
   };
   auto kvar = [&](int ks) -> int { return C != 16 ? 0 : (ks == 1 ? dx : (ks == 4 ? 0 : d1)); };
   const int lane_o = l15 * C + c0 + 4 * q;
-  int poff[P];
-#pragma unroll
-  for (int i = 0; i < P; ++i) {
-    const int p = (wave * P + i) * 16 + l15;
-    poff[i] = (p / TW) * ROWB + (p % TW) * PSB + q_slot;
-  }
+  constexpr int PD = G::PD, PG = G::PG;      // pixel tiles per data-gradient wave, and per group sharing a filter fragment
+  // byte offset of pixel tile 0 of the wave inside a plane; tile i of the wave adds tile_off(i)
+  const int poff0 = ((rw * PD * 16 + l15) / TW) * ROWB + ((rw * PD * 16 + l15) % TW) * PSB + q_slot;
+  auto tile_off = [](int i) constexpr -> int { return TW >= 16 ? ((i * 16) / TW) * ROWB + ((i * 16) % TW) * PSB : (i * 16 / TW) * ROWB; };
   // filter gradient: this wave's output-channel tile and share of the band's K steps; transposed-read
   // lane addresses: lane 4 j + i of a group points at pixel 4 g + j of the step, channels 4 i .. 4 i + 3
-  const int wp = wave % WP, wx = wave / WP;
-  const int tr_pix = 4 * q + ((lane >> 2) & 3), tr_c = lane & 3;
-  const int lane_xa = tr_pix * XPB + tr_c * 8;
-  const int lane_db = tr_pix * PSB + wp * 32 + tr_c * 8;
+  const int wp = CO_T == 1 ? 0 : rw, wx = CO_T == 1 ? rw : 0;
+  const int tr_j = (lane >> 2) & 3, tr_c = lane & 3;
+  const int lane_xa = (4 * q + tr_j) * XPB + tr_c * 8;
+  const int lane_db = (TW == 8 ? (q >> 1) * ROWB + (4 * (q & 1) + tr_j) * PSB : (4 * q + tr_j) * PSB) + wp * 32 + tr_c * 8;
 
-  floatx4 accw[9];
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap) accw[tap] = floatx4{0.f, 0.f, 0.f, 0.f};
   floatx4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
+  constexpr int RS = G::RED_STRIDE;
+  float* s_red = reinterpret_cast<float*>(smem_b);   // [WX][9][16][RS], after the last band
 
-  int t_next = t + gpz;
-  while (t < total_tiles) {
-    const int n = t / bands;
-    const int oy0 = (t - n * bands) * TH;
-    const long long obase = ((long long)(n * a.H + oy0) * TW) * C;
-
-    write_band(((long long)(n * a.H + oy0 - 1) * a.W) * C);
-    __syncthreads();
-    if (t_next < total_tiles) load_band(t_next);   // in flight during both MFMA phases
-
-    // ---- data gradient: M = pixels, N = the block's input channels, K = taps x C --------------------------
-    {
-      // mask / x-hat source of THIS band's pixel tiles (the extra gradient of a first block is read in the epilogue)
-      floatx4 cur_xv[P];
-#pragma unroll
-      for (int i = 0; i < P; ++i) cur_xv[i] = *reinterpret_cast<const floatx4*>(a.x + obase + (long long)((wave * P + i) * 16) * C + lane_o);
-      floatx4 acc[P];
-#pragma unroll
-      for (int i = 0; i < P; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-      // Walk (K step, pixel tile); the operand reads of the next unit are in flight while the six MFMAs of this one run.
-      constexpr int UNITS = KS * P;
-      uintx4 ah[2], am[2], al[2], wl[2];
-      auto read_unit = [&](int u, int buf) {
-        const int ks = u / P, i = u % P;
-        const unsigned char* p = s_dy + poff[i] + kvar(ks) + kconst(ks);
-        ah[buf] = *reinterpret_cast<const uintx4*>(p);
-        am[buf] = *reinterpret_cast<const uintx4*>(p + PLANE);
-        al[buf] = *reinterpret_cast<const uintx4*>(p + 2 * PLANE);
-        if (i == 0) wl[ks & 1] = s_wl[ks * 64 + lane];
-      };
-      read_unit(0, 0);
-#pragma unroll
-      for (int u = 0; u < UNITS; ++u) {
-        const int ks = u / P, i = u % P, b = u & 1;
-        if (u + 1 < UNITS) read_unit(u + 1, b ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-        const bf16x8 whv = __builtin_bit_cast(bf16x8, wh[ks]);
-        const bf16x8 wmv = __builtin_bit_cast(bf16x8, wm[ks]);
-        const bf16x8 wlv = __builtin_bit_cast(bf16x8, wl[ks & 1]);
-        const bf16x8 ahv = __builtin_bit_cast(bf16x8, ah[b]), amv = __builtin_bit_cast(bf16x8, am[b]), alv = __builtin_bit_cast(bf16x8, al[b]);
-        // small terms first, then the large ones
-        acc[i] = DTF_MFMA_BF16(wlv, ahv, acc[i]);
-        acc[i] = DTF_MFMA_BF16(whv, alv, acc[i]);
-        acc[i] = DTF_MFMA_BF16(wmv, amv, acc[i]);
-        acc[i] = DTF_MFMA_BF16(wmv, ahv, acc[i]);
-        acc[i] = DTF_MFMA_BF16(whv, amv, acc[i]);
-        acc[i] = DTF_MFMA_BF16(whv, ahv, acc[i]);
-        __builtin_amdgcn_sched_barrier(0);
+  // The persistent band loop, once per role: stage, barrier, request the next band, the role's MFMA phase, barrier.
+  auto band_loop = [&](auto&& phase) __attribute__((always_inline)) {
+    int t_next = t + gpz;
+    while (t < total_tiles) {
+      const int n = t / bands;
+      const int oy0 = (t - n * bands) * TH;
+      write_band(((long long)(n * a.H + oy0 - 1) * a.W) * C);
+      __syncthreads();
+      if (t_next < total_tiles) {   // in flight during the MFMA phase
+        load_band(t_next);
+        if (RES) load_res(t_next);
       }
-      // epilogue: ReLU mask and x-hat from the raw x, statistics, 16-byte stores
-      const floatx4 esc = *reinterpret_cast<const floatx4*>(s_co + 4 * q), esh = *reinterpret_cast<const floatx4*>(s_co + 16 + 4 * q);
-      const floatx4 emu = *reinterpret_cast<const floatx4*>(s_co + 32 + 4 * q), ers = *reinterpret_cast<const floatx4*>(s_co + 48 + 4 * q);
-#pragma unroll
-      for (int i = 0; i < P; ++i) {
-        const int p0 = (wave * P + i) * 16;
-        floatx4 v = acc[i];
-        if (a.extra) v += *reinterpret_cast<const floatx4*>(a.extra + obase + (long long)p0 * C + lane_o);
-        const floatx4 x = cur_xv[i];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = (x[r] * esc[r] + esh[r] > 0.f) ? v[r] : 0.f;
-          st1[r] += v[r];
-          st2[r] += v[r] * ((x[r] - emu[r]) * ers[r]);
-        }
-        *reinterpret_cast<floatx4*>(a.g + obase + (long long)p0 * C + lane_o) = v;
-      }
+      phase(((long long)(n * a.H + oy0) * TW) * C);
+      __syncthreads();   // all waves are done with this band's planes
+      t = t_next;
+      t_next += gpz;
     }
+  };
 
-    if (RES && t_next < total_tiles) load_res(t_next);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- filter gradient: M = input channels, N = output channels, K = pixels of the band ----------------------
-    {
+  if (dgrad_wave) {
+    // h and m parts of the filter slice stay in registers
+    uintx4 wh[KS], wm[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      wh[ks] = wsrc[((ks * CO_T + z) * 3 + 0) * 64 + lane];
+      wm[ks] = wsrc[((ks * CO_T + z) * 3 + 1) * 64 + lane];
+    }
+    band_loop([&](long long obase) __attribute__((always_inline)) {
+      // ---- data gradient: M = pixels, N = the block's input channels, K = taps x C ------------------------
+      static_assert((PG * 16) % TW == 0, "a group of pixel tiles is whole rows");
+#pragma unroll 1
+      for (int grp = 0; grp < PD / PG; ++grp) {
+        const unsigned char* s_grp = s_dy + poff0 + grp * ((PG * 16) / TW) * ROWB;
+        // mask / x-hat source of the group's pixel tiles (the extra gradient of a first block is read in the epilogue)
+        floatx4 cur_xv[PG], acc[PG];
+#pragma unroll
+        for (int i = 0; i < PG; ++i) {
+          cur_xv[i] = *reinterpret_cast<const floatx4*>(a.x + obase + (long long)((rw * PD + grp * PG + i) * 16) * C + lane_o);
+          acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+        // Walk (K step, pixel tile); the operand reads of the next unit are in flight while the six MFMAs of this one run.
+        constexpr int UNITS = KS * PG;
+        uintx4 ah[2], am[2], al[2], wl[2];
+        auto read_unit = [&](int u, int buf) {
+          const int ks = u / PG, i = u % PG;
+          const unsigned char* p = s_grp + tile_off(i) + kvar(ks) + kconst(ks);
+          ah[buf] = *reinterpret_cast<const uintx4*>(p);
+          am[buf] = *reinterpret_cast<const uintx4*>(p + PLANE);
+          al[buf] = *reinterpret_cast<const uintx4*>(p + 2 * PLANE);
+          if (i == 0) wl[ks & 1] = s_wl[ks * 64 + lane];
+        };
+        read_unit(0, 0);
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+          const int ks = u / PG, i = u % PG, b = u & 1;
+          if (u + 1 < UNITS) read_unit(u + 1, b ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8 whv = __builtin_bit_cast(bf16x8, wh[ks]);
+          const bf16x8 wmv = __builtin_bit_cast(bf16x8, wm[ks]);
+          const bf16x8 wlv = __builtin_bit_cast(bf16x8, wl[ks & 1]);
+          const bf16x8 ahv = __builtin_bit_cast(bf16x8, ah[b]), amv = __builtin_bit_cast(bf16x8, am[b]), alv = __builtin_bit_cast(bf16x8, al[b]);
+          // small terms first, then the large ones
+          acc[i] = DTF_MFMA_BF16(wlv, ahv, acc[i]);
+          acc[i] = DTF_MFMA_BF16(whv, alv, acc[i]);
+          acc[i] = DTF_MFMA_BF16(wmv, amv, acc[i]);
+          acc[i] = DTF_MFMA_BF16(wmv, ahv, acc[i]);
+          acc[i] = DTF_MFMA_BF16(whv, amv, acc[i]);
+          acc[i] = DTF_MFMA_BF16(whv, ahv, acc[i]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // epilogue: ReLU mask and x-hat from the raw x, statistics, 16-byte stores
+        __builtin_amdgcn_sched_barrier(0);   // the coefficient reads stay behind the MFMA loop: registers
+        const floatx4 esc = *reinterpret_cast<const floatx4*>(s_co + 4 * q), esh = *reinterpret_cast<const floatx4*>(s_co + 16 + 4 * q);
+        const floatx4 emu = *reinterpret_cast<const floatx4*>(s_co + 32 + 4 * q), ers = *reinterpret_cast<const floatx4*>(s_co + 48 + 4 * q);
+#pragma unroll
+        for (int i = 0; i < PG; ++i) {
+          const int p0 = (rw * PD + grp * PG + i) * 16;
+          floatx4 v = acc[i];
+          if (a.extra) v += *reinterpret_cast<const floatx4*>(a.extra + obase + (long long)p0 * C + lane_o);
+          const floatx4 x = cur_xv[i];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = (x[r] * esc[r] + esh[r] > 0.f) ? v[r] : 0.f;
+            st1[r] += v[r];
+            st2[r] += v[r] * ((x[r] - emu[r]) * ers[r]);
+          }
+          *reinterpret_cast<floatx4*>(a.g + obase + (long long)p0 * C + lane_o) = v;
+        }
+      }
+    });
+  } else {
+    floatx4 accw[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) accw[tap] = floatx4{0.f, 0.f, 0.f, 0.f};
+    band_loop([&](long long) __attribute__((always_inline)) {
+      // ---- filter gradient: M = input channels, N = output channels, K = pixels of the band --------------------
       constexpr int MYSTEPS = G::WSTEPS / WX;
       constexpr int WUNITS = MYSTEPS * 9;
       uintx2 xa[3][2];        // A: relu(bn(x)) parts of the current step
       uintx2 db[2][3][2];     // B: dy parts of the current / next (step, tap)
       auto read_a = [&](int ms) {
-        const int s = wx + ms * WX;
-        const unsigned char* p = s_x + lane_xa + s * 32 * XPB;
+        const unsigned char* p = s_x + lane_xa + (wx + ms * WX) * 32 * XPB;
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
           xa[part][0] = lds_read_tr(p + part * XPLANE);
@@ -407,18 +427,11 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_split_kernel(ConvBwdFusedArgs
       };
       auto read_b = [&](int u, int buf) {
         const int ms = u / 9, tap = u % 9;
-        const int s = wx + ms * WX;
         const int kh = tap / 3, kw = tap % 3;
-        // dy[pixel - (tap - 1)]: halo position (row + 2 - kh, col + 2 - kw)
-        const unsigned char* p0;
-        const unsigned char* p1;
-        if (TW == 16) {   // a step is two rows of 16 pixels
-          p0 = s_dy + lane_db + (2 * s + 2 - kh) * ROWB + (2 - kw) * PSB;
-          p1 = p0 + ROWB;
-        } else {          // a step is one row of 32 pixels
-          p0 = s_dy + lane_db + (s + 2 - kh) * ROWB + (2 - kw) * PSB;
-          p1 = p0 + 16 * PSB;
-        }
+        // dy[pixel - (tap - 1)]: halo position (row + 2 - kh, col + 2 - kw); a step is 32 / TW whole rows
+        constexpr int SROWS = 32 / TW > 0 ? 32 / TW : 1;
+        const unsigned char* p0 = s_dy + lane_db + (wx + ms * WX) * (SROWS * ROWB) + (2 - kh) * ROWB + (2 - kw) * PSB;
+        const unsigned char* p1 = p0 + (TW == 32 ? 16 * PSB : (16 / TW) * ROWB);
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
           db[buf][part][0] = lds_read_tr(p0 + part * PLANE);
@@ -443,25 +456,21 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_split_kernel(ConvBwdFusedArgs
         __builtin_amdgcn_sched_barrier(0);
         if (tap == 8 && u + 1 < WUNITS) read_a(u / 9 + 1);
       }
-    }
-    __syncthreads();   // all waves are done with this band's planes
-    t = t_next;
-    t_next += gpz;
+    });
+    // accumulators -> LDS; the planes are free (barrier at the end of the last band)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        s_red[((wx * 9 + tap) * 16 + 4 * q + r) * RS + wp * 16 + l15] = accw[tap][r];
   }
 
   // ---- statistics (the filter's l part in LDS is no longer needed: its space parks the wave rows) --------
   if (a.gsums) {
-    floatx4 s1v[1] = {st1}, s2v[1] = {st2};
+    floatx4 s1v[1] = {st1}, s2v[1] = {st2};   // zeros from the filter-gradient waves
     block_stat_flush<1, 4>(reinterpret_cast<float*>(s_wl), s1v, s2v, a.gsums, C, c0, kStatGridBwd);
   }
-  // ---- filter gradient flush: accumulators -> LDS, sum the pixel-split partials, coalesced stores / atomics ----
-  constexpr int RS = G::RED_STRIDE;
-  float* s_red = reinterpret_cast<float*>(smem_b);   // [WX][9][16][RS]; the planes are free (barrier above)
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      s_red[((wx * 9 + tap) * 16 + 4 * q + r) * RS + wp * 16 + l15] = accw[tap][r];
+  // ---- filter gradient flush: sum the pixel-split partials, coalesced stores / atomics ---------------------
   __syncthreads();
   // with dw_part: plain stores into copy jblk of the whole gradient (this block's rows of it)
   float* dw = a.dw_part ? a.dw_part + (size_t)jblk * (9 * C * C) : a.dw + (size_t)(blockIdx.x & (kStatSlots - 1)) * a.dw_slot_stride;
@@ -522,12 +531,13 @@ static size_t bs_dispatch(const ConvBwdFusedArgs& a, hipStream_t stream, int* co
     if (!a.dy_bn.sums || !a.dy_gsums) throw std::runtime_error("conv_bwd_split: the BatchNorm prologue needs its statistics");
     if (a.dy_res) {
       if (!a.dy_out) throw std::runtime_error("conv_bwd_split: dy_res needs dy_out");
+      // three prefetched tensors: 4-row bands keep them in registers (8-row bands spill 40-50 of them)
       if (a.dy_res_mode == 1) {
-        if (a.C == 16) return launch_bs<16, 32, 8, true, 2>(a, stream, copies);
-        return launch_bs<32, 16, 8, true, 2>(a, stream, copies);
+        if (a.C == 16) return launch_bs<16, 32, 4, true, 2>(a, stream, copies);
+        return launch_bs<32, 16, 4, true, 2>(a, stream, copies);
       }
-      if (a.C == 16) return launch_bs<16, 32, 8, true, 1>(a, stream, copies);
-      return launch_bs<32, 16, 8, true, 1>(a, stream, copies);
+      if (a.C == 16) return launch_bs<16, 32, 4, true, 1>(a, stream, copies);
+      return launch_bs<32, 16, 4, true, 1>(a, stream, copies);
     }
     if (a.C == 16) return launch_bs<16, 32, 8, true>(a, stream, copies);
     return launch_bs<32, 16, 8, true>(a, stream, copies);

@@ -119,7 +119,12 @@ class ResNetHipStep(StepProgramBase):
         self._pk_fwd: Dict[str, Tuple[int, int]] = {}
         self._pk_bwd: Dict[str, Tuple[int, int]] = {}
         convs = [("conv0/conv", 3, 16, 1)] + [(c.weight, c.cin, c.cout, c.stride) for blk in self.blocks for c in (blk.conv1, blk.conv2)]
+        in_hw = {c.weight: c.in_hw for blk in self.blocks for c in (blk.conv1, blk.conv2)}
+        # the split-operand backward kernels need the fused backward pass and static band scheduling
+        self._split_backward = (os.environ.get("DTF_SPLIT_BWD", "1") != "0" and os.environ.get("DTF_BWD_FUSED", "1") != "0"
+                                and os.environ.get("DTF_DYNAMIC_TILES", "0") == "0")
         self._split_fwd = set()     # layers whose forward pass runs on the split-operand kernel
+        self._split_bwd = set()     # layers whose fused backward pass does
         for name, cin, cout, stride in convs:
             if self.matmul == "bf16x6" and name != "conv0/conv" and nv.split_supported(cin, cout, stride):
                 nfl = int(nv.hip().packed_split_floats(cin))
@@ -131,9 +136,15 @@ class ResNetHipStep(StepProgramBase):
             self._pk_fwd[name] = (off, nfl)
             off += nfl
             if training and name != "conv0/conv":
-                nfl = nv.packed_floats(3, cin, cout, True)
+                hw = in_hw[name]
+                if name in self._split_fwd and self._split_backward and nv.hip().conv_bwd_split_supported(B, hw, hw, cin):
+                    nfl = int(nv.hip().packed_split_floats(cin))
+                    self._split_bwd.add(name)
+                    entries.append((a.offsets[name], off, 3, cin, cout, 3, nfl))
+                else:
+                    nfl = nv.packed_floats(3, cin, cout, True)
+                    entries.append((a.offsets[name], off, 3, cin, cout, 1, nfl))
                 self._pk_bwd[name] = (off, nfl)
-                entries.append((a.offsets[name], off, 3, cin, cout, 1, nfl))
                 off += nfl
         self.packed = torch.empty(off, **f32)
         table = np.zeros(len(entries), dtype=PACK_DTYPE)
@@ -309,7 +320,8 @@ class ResNetHipStep(StepProgramBase):
                     kw["tile_counters"] = self._tile_ctr[self._tile_ctr_used:self._tile_ctr_used + nctr]
                     self._tile_ctr_used += nctr
                 return nv.conv_bwd_fused(dout, x, bn.fwd, self._wpk(conv.weight, True), dw_slot_view(conv.weight), bn.gsums,
-                                         slot_stride=a.total, extra=extra, out=out, parts=self._parts, **kw)
+                                         slot_stride=a.total, extra=extra, out=out, parts=self._parts,
+                                         split=conv.weight in self._split_bwd, **kw)
             assert dout_bn is None and shortcut is None
             wgrad(x, dout, conv.weight, s, bn.fwd)
             _, pb, _ = same_pad(x.shape[1], 3, s)
