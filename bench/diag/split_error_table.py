@@ -1,6 +1,7 @@
 """Error of the split-operand ("bf16x6") path next to the exact-fp32 path, both against fp64 on the
 same inputs: (1) every stride-1 layer shape of the network, forward kernel with BatchNorm prologue,
-identity residual and statistics, batch 1024; (2) a whole ResNet-20 training step at batch 256 and
+identity residual and statistics, batch 1024, and the fused backward kernel (data gradient and filter
+gradient) at batch 256; (2) a whole ResNet-20 training step at batch 256 and
 1024: loss and per-tensor gradient error. The rule the split path is held to: max error <= 2 x the
 exact path's."""
 import sys
@@ -32,6 +33,37 @@ for hw, c in [(32, 16), (16, 32), (8, 64)]:
         esp = max(esp, T.rel(nv.conv_fprop(x, nv.pack_split_weights(wt), ks=3, cout=c, in_bn=bn, res_mode=nv.RES_IDENT, res=res, split=True), want))
     worst_ratio = max(worst_ratio, esp / e32)
     print(f"   {hw}x{hw}x{c:<3d}     {e32:.3e}     {esp:.3e}   {esp / e32:.2f}")
+
+print("1b. fused backward kernel, batch 256: data gradient g and filter gradient dW, same measure (three seeds each)")
+print("   shape        g exact     g bf16x6   ratio    dW exact    dW bf16x6  ratio")
+for hw, c in [(32, 16), (16, 32), (8, 64)]:
+    if not nv.hip().conv_bwd_split_supported(256, hw, hw, c):
+        continue
+    eg32 = egsp = ew32 = ewsp = 0.0
+    for seed in range(3):
+        b = 256
+        x = T.rnd(b, hw, hw, c, scale=2.0, seed=3 + 10 * seed) + 0.3
+        gamma, beta = T.rnd(c, seed=4 + 10 * seed).abs() + 0.5, T.rnd(c, scale=0.2, seed=5 + 10 * seed)
+        wt = T.rnd(3, 3, c, c, scale=0.1, seed=6 + 10 * seed)
+        dy = T.rnd(b, hw, hw, c, seed=7 + 10 * seed)
+        u = ref.batch_norm(x.double(), gamma.double(), beta.double())
+        a = torch.relu(u).requires_grad_(True)
+        wd = wt.double().requires_grad_(True)
+        da, dw = torch.autograd.grad(T.conv2d_same_unfold(a, wd, 1), (a, wd), dy.double())
+        want_g = torch.where(u > 0, da, torch.zeros_like(da))
+        bn = T.bn_state_for(x, gamma, beta)
+        n = wt.numel()
+        for split in (False, True):
+            slots = torch.zeros(nv.STAT_SLOTS, n, device="cuda")
+            wpk = nv.pack_split_weights(wt, flip=True) if split else nv.pack_weights(wt, flip=True)
+            got = nv.conv_bwd_fused(dy, x, bn, wpk, slots[0].view(3, 3, c, c), nv.new_stats(c, "cuda"), slot_stride=n, split=split)
+            eg, ew = T.rel(got, want_g), T.rel(slots.double().sum(0).view(dw.shape), dw)
+            if split:
+                egsp, ewsp = max(egsp, eg), max(ewsp, ew)
+            else:
+                eg32, ew32 = max(eg32, eg), max(ew32, ew)
+    worst_ratio = max(worst_ratio, egsp / eg32, ewsp / ew32)
+    print(f"   {hw}x{hw}x{c:<3d}     {eg32:.3e}   {egsp:.3e}  {egsp / eg32:.2f}     {ew32:.3e}   {ewsp:.3e}  {ewsp / ew32:.2f}")
 
 ref.conv2d_same = T.conv2d_same_unfold
 print("2. ResNet-20 training step against fp64 autograd: loss error, and over the 65 parameter tensors the worst and the")

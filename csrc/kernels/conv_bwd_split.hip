@@ -417,6 +417,12 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_split_kernel(ConvBwdFusedArgs
       constexpr int WUNITS = MYSTEPS * 9;
       uintx2 xa[3][2];        // A: relu(bn(x)) parts of the current step
       uintx2 db[2][3][2];     // B: dy parts of the current / next (step, tap)
+      // The band's sum is formed in accumulators of its own and added to the running total once: the
+      // total then takes one rounding per band instead of one per MFMA (a few hundred per workgroup),
+      // which is what the error of a sum over 10^5 pixels is made of.
+      floatx4 accb[9];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) accb[tap] = floatx4{0.f, 0.f, 0.f, 0.f};
       auto read_a = [&](int ms) {
         const unsigned char* p = s_x + lane_xa + (wx + ms * WX) * 32 * XPB;
 #pragma unroll
@@ -447,15 +453,17 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_split_kernel(ConvBwdFusedArgs
         __builtin_amdgcn_sched_barrier(0);
         const bf16x8 xh = frag8(xa[0][0], xa[0][1]), xm = frag8(xa[1][0], xa[1][1]), xl = frag8(xa[2][0], xa[2][1]);
         const bf16x8 dh = frag8(db[b][0][0], db[b][0][1]), dm = frag8(db[b][1][0], db[b][1][1]), dl = frag8(db[b][2][0], db[b][2][1]);
-        accw[tap] = DTF_MFMA_BF16(xl, dh, accw[tap]);
-        accw[tap] = DTF_MFMA_BF16(xh, dl, accw[tap]);
-        accw[tap] = DTF_MFMA_BF16(xm, dm, accw[tap]);
-        accw[tap] = DTF_MFMA_BF16(xm, dh, accw[tap]);
-        accw[tap] = DTF_MFMA_BF16(xh, dm, accw[tap]);
-        accw[tap] = DTF_MFMA_BF16(xh, dh, accw[tap]);
+        accb[tap] = DTF_MFMA_BF16(xl, dh, accb[tap]);
+        accb[tap] = DTF_MFMA_BF16(xh, dl, accb[tap]);
+        accb[tap] = DTF_MFMA_BF16(xm, dm, accb[tap]);
+        accb[tap] = DTF_MFMA_BF16(xm, dh, accb[tap]);
+        accb[tap] = DTF_MFMA_BF16(xh, dm, accb[tap]);
+        accb[tap] = DTF_MFMA_BF16(xh, dh, accb[tap]);
         __builtin_amdgcn_sched_barrier(0);
         if (tap == 8 && u + 1 < WUNITS) read_a(u / 9 + 1);
       }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) accw[tap] += accb[tap];
     });
     // accumulators -> LDS; the planes are free (barrier at the end of the last band)
 #pragma unroll
