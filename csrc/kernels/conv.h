@@ -170,12 +170,16 @@ constexpr int kBwdTileCounters = 32;   // 8 XCDs x up to 4 channel splits
 bool conv_bwd_fused_supported(int B, int H, int W, int C);
 size_t conv_bwd_fused(const ConvBwdFusedArgs& a, hipStream_t stream);
 int conv_bwd_fused_copies(const ConvBwdFusedArgs& a);
-// Opt-in "bf16x6" variant for the 16- and 32-channel layers (conv_bwd_split.hip): both products on the
+// Opt-in "bf16x6" variant (conv_bwd_split.hip, conv_bwd_split_pc.hip): both products on the
 // bf16 matrix pipe with operands split three ways, fp32 accumulation. `wpk_t` is then the output of
 // pack_split_weights with transpose_flip = 1; no dynamic band scheduling.
 bool conv_bwd_split_supported(int B, int H, int W, int C);
 size_t conv_bwd_split(const ConvBwdFusedArgs& a, hipStream_t stream);
 int conv_bwd_split_copies(const ConvBwdFusedArgs& a);
+// 64-channel instance: producer / consumer waves, one workgroup per CU (conv_bwd_split_pc.hip); reached
+// through conv_bwd_split. copies != nullptr: no launch, *copies = gradient copies the launch would fill.
+bool conv_bwd_split_pc_supported(int B, int H, int W, int C);
+size_t conv_bwd_split_pc(const ConvBwdFusedArgs& a, hipStream_t stream, int* copies);
 
 // ---- stem of the CIFAR ResNet: 3x3, 3 -> 16 channels, SAME, 32x32 images (conv_stem.hip)
 // forward: y = conv(x, w), sums (nullable) += per-channel (sum, sum of squares) of y in the

@@ -28,18 +28,6 @@
 namespace dtf {
 namespace {
 
-typedef short shortx4 __attribute__((ext_vector_type(4)));
-
-// 4 pixels x 16 channels (bf16) per 16-lane group, delivered channel-major: lane i of the group gets
-// channel i of the four pixels whose addresses lanes 4 j .. 4 j + 3 supply (8 bytes each).
-__device__ __forceinline__ uintx2 lds_read_tr(const unsigned char* p) {
-  return __builtin_bit_cast(uintx2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                        (shortx4 __attribute__((address_space(3)))*)(const_cast<unsigned char*>(p))));
-}
-__device__ __forceinline__ bf16x8 frag8(const uintx2& lo, const uintx2& hi) {
-  return __builtin_bit_cast(bf16x8, uintx4{lo[0], lo[1], hi[0], hi[1]});
-}
-
 template <int C, int TW, int TH>
 struct BSplit {
   using PL = SplitPlanes<C, TW, TH>;
@@ -528,13 +516,16 @@ size_t launch_bs(const ConvBwdFusedArgs& a, hipStream_t stream, int* copies) {
 
 bool conv_bwd_split_supported(int B, int H, int W, int C) {
   (void)B;
-  return H == W && H % 8 == 0 && ((C == 16 && W == 32) || (C == 32 && W == 16));
+  return (H == W && H % 8 == 0 && ((C == 16 && W == 32) || (C == 32 && W == 16))) || conv_bwd_split_pc_supported(B, H, W, C);
 }
 
 static size_t bs_dispatch(const ConvBwdFusedArgs& a, hipStream_t stream, int* copies) {
   if (!conv_bwd_split_supported(a.B, a.H, a.W, a.C)) throw std::runtime_error("conv_bwd_split: unsupported shape");
   if (!a.dy || !a.x || !a.wpk_t || !a.g || !a.dw || !a.bn.sums) throw std::runtime_error("conv_bwd_split: null operand");
   if (a.tile_counters) throw std::runtime_error("conv_bwd_split: no dynamic band scheduling");
+  if (a.dy_x && (!a.dy_bn.sums || !a.dy_gsums)) throw std::runtime_error("conv_bwd_split: the BatchNorm prologue needs its statistics");
+  if (a.dy_res && (!a.dy_x || !a.dy_out)) throw std::runtime_error("conv_bwd_split: dy_res needs dy_x and dy_out");
+  if (a.C == 64) return conv_bwd_split_pc(a, stream, copies);
   if (a.dy_x) {
     if (!a.dy_bn.sums || !a.dy_gsums) throw std::runtime_error("conv_bwd_split: the BatchNorm prologue needs its statistics");
     if (a.dy_res) {

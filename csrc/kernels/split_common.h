@@ -90,4 +90,16 @@ __device__ __forceinline__ void split3(const floatx4& v, uintx2& h, uintx2& m, u
   }
 }
 
+typedef short shortx4 __attribute__((ext_vector_type(4)));
+
+// 4 pixels x 16 channels (bf16) per 16-lane group, delivered channel-major: lane i of the group gets
+// channel i of the four pixels whose addresses lanes 4 j .. 4 j + 3 supply (8 bytes each).
+__device__ __forceinline__ uintx2 lds_read_tr(const unsigned char* p) {
+  return __builtin_bit_cast(uintx2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                        (shortx4 __attribute__((address_space(3)))*)(const_cast<unsigned char*>(p))));
+}
+__device__ __forceinline__ bf16x8 frag8(const uintx2& lo, const uintx2& hi) {
+  return __builtin_bit_cast(bf16x8, uintx4{lo[0], lo[1], hi[0], hi[1]});
+}
+
 }  // namespace dtf
