@@ -525,7 +525,26 @@ static size_t bs_dispatch(const ConvBwdFusedArgs& a, hipStream_t stream, int* co
   if (a.tile_counters) throw std::runtime_error("conv_bwd_split: no dynamic band scheduling");
   if (a.dy_x && (!a.dy_bn.sums || !a.dy_gsums)) throw std::runtime_error("conv_bwd_split: the BatchNorm prologue needs its statistics");
   if (a.dy_res && (!a.dy_x || !a.dy_out)) throw std::runtime_error("conv_bwd_split: dy_res needs dy_x and dy_out");
-  if (a.C == 64) return conv_bwd_split_pc(a, stream, copies);
+  // Producer / consumer waves (conv_bwd_split_pc.hip): always at 64 channels; at 16 channels for the
+  // shortcut variants (three prefetched tensors: 8-row bands there against 4-row bands here, 90-93 us
+  // against 96-98 us in the step at batch 1024). Everything else is faster with two workgroups per CU
+  // (16 channels + BatchNorm prologue 93 against 110 us, 32 channels 60 against 76 us).
+  // DTF_BWD_SPLIT_PC=16,32 forces that organisation for a channel count (measurements).
+  static const int pc_mask = [] {
+    int m = 64;
+    if (const char* e = std::getenv("DTF_BWD_SPLIT_PC"))
+      for (const char* p = e; *p;) {
+        if (*p >= '0' && *p <= '9') {
+          const int v = std::atoi(p);
+          if (v == 16 || v == 32) m |= v;
+          while (*p >= '0' && *p <= '9') ++p;
+        } else {
+          ++p;
+        }
+      }
+    return m;
+  }();
+  if ((a.C & pc_mask) || (a.C == 16 && a.dy_res)) return conv_bwd_split_pc(a, stream, copies);
   if (a.dy_x) {
     if (!a.dy_bn.sums || !a.dy_gsums) throw std::runtime_error("conv_bwd_split: the BatchNorm prologue needs its statistics");
     if (a.dy_res) {

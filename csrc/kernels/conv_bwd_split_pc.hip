@@ -8,9 +8,10 @@
 //              registers, no vector-memory traffic besides the epilogue's
 //   waves 2-3  filter gradient of the same band (transposed reads, conv_bwd_split.hip): one or two
 //              output-channel tiles each
-//   waves 4-7  producers: write band j + 1 (held in registers since the previous iteration) into set
+//   waves 4-7  producers: write band j + 1 (held in registers since two iterations ago) into set
 //              (j + 1) % 2 - BatchNorm backward, shortcut term, BatchNorm + ReLU, three-way split - and
-//              request band j + 2; one barrier per band
+//              request band j + 3 (memory latency is longer than one band's MFMA phase, so two bands are
+//              in flight); one barrier per band
 // so the matrix waves never wait for memory or for staging, and staging costs them only the issue
 // slots it takes on their SIMD. (A 64-channel filter slice streamed from L2 instead would queue its
 // refills behind the prefetch loads - vector memory operations retire in order - and a second
@@ -154,11 +155,15 @@ __global__ __launch_bounds__(512, 1) void conv_bwd_split_pc_kernel(ConvBwdFusedA
     const int r_goff0 = (((d_r0 - 1) >> 1) * (TW / 2) + (d_ix >> 1)) * (2 * C) + C / 2 + d_c4 * 4;
     auto r_goff = [&](int k) -> int { return r_goff0 + k * (RPK / 2) * (TW / 2) * (2 * C); };
 
-    floatx4 pf_d[G::NPF_D], pf_x[G::NPF_X];
-    floatx4 pf_c[DYBN ? G::NPF_D : 1];
-    floatx4 pf_r[RES ? G::NPF_D : 1];
-    unsigned okbits = 0;
-    auto load_band = [&](int t) __attribute__((always_inline)) {
+    // a band in flight: its chunks in registers between the loads and the staging
+    struct Pf {
+      floatx4 d[G::NPF_D], x[G::NPF_X];
+      floatx4 c[DYBN ? G::NPF_D : 1];
+      floatx4 r[RES ? G::NPF_D : 1];
+      unsigned ok;
+    };
+    Pf pfa, pfb;   // two bands are in flight: memory latency is longer than one band's MFMA phase
+    auto load_band = [&](int t, Pf& pf) __attribute__((always_inline)) {
       const int n = t / bands;
       const int oy0 = (t - n * bands) * TH;
       const long long doff = ((long long)(n * a.H + oy0 - 1) * a.W) * C;
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(512, 1) void conv_bwd_split_pc_kernel(ConvBwdFusedA
       const float* x0 = a.x + ((long long)(n * a.H + oy0) * a.W) * C;
       const float* r0 = !RES ? nullptr
                              : (RES == 2 ? a.dy_res + ((long long)(n * (a.H / 2) + oy0 / 2) * (TW / 2)) * (2 * C) : a.dy_res + doff);
-      okbits = 0;
+      pf.ok = 0;
 #pragma unroll
       for (int k = 0; k < G::NPF_D; ++k) {
         const int iy = oy0 - 1 + d_row(k);
@@ -174,17 +179,17 @@ __global__ __launch_bounds__(512, 1) void conv_bwd_split_pc_kernel(ConvBwdFusedA
         if (d_ok(k) && iy >= 0 && iy < a.H) {
           v = *reinterpret_cast<const floatx4*>(d0 + d_goff(k));
           if (DYBN) {
-            pf_c[k] = *reinterpret_cast<const floatx4*>(a.dy_x + doff + d_goff(k));
-            okbits |= 1u << k;
+            pf.c[k] = *reinterpret_cast<const floatx4*>(a.dy_x + doff + d_goff(k));
+            pf.ok |= 1u << k;
           }
-          if (RES) pf_r[k] = *reinterpret_cast<const floatx4*>(r0 + (RES == 2 ? r_goff(k) : d_goff(k)));
+          if (RES) pf.r[k] = *reinterpret_cast<const floatx4*>(r0 + (RES == 2 ? r_goff(k) : d_goff(k)));
         }
-        pf_d[k] = v;
+        pf.d[k] = v;
       }
 #pragma unroll
-      for (int k = 0; k < G::NPF_X; ++k) pf_x[k] = *reinterpret_cast<const floatx4*>(x0 + x_goff0 + k * XPK * C);
+      for (int k = 0; k < G::NPF_X; ++k) pf.x[k] = *reinterpret_cast<const floatx4*>(x0 + x_goff0 + k * XPK * C);
     };
-    auto write_band = [&](int t, unsigned char* set) __attribute__((always_inline)) {
+    auto write_band = [&](int t, unsigned char* set, const Pf& pf) __attribute__((always_inline)) {
       const int n = t / bands;
       const int oy0 = (t - n * bands) * TH;
       const long long doff = ((long long)(n * a.H + oy0 - 1) * a.W) * C;
@@ -193,18 +198,18 @@ __global__ __launch_bounds__(512, 1) void conv_bwd_split_pc_kernel(ConvBwdFusedA
 #pragma unroll
       for (int k = 0; k < G::NPF_D; ++k)
         if (d_ok(k)) {
-          floatx4 v = pf_d[k];
-          if (DYBN && ((okbits >> k) & 1u)) {
+          floatx4 v = pf.d[k];
+          if (DYBN && ((pf.ok >> k) & 1u)) {
             // BatchNorm backward of the following layer, applied while staging (zero padding stays zero)
             const int ch = d_c4 * 4;
             const floatx4 ca = *reinterpret_cast<const floatx4*>(s_dco + ch);
             const floatx4 cb = *reinterpret_cast<const floatx4*>(s_dco + C + ch);
             const floatx4 cc = *reinterpret_cast<const floatx4*>(s_dco + 2 * C + ch);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ca[e] * v[e] + (cb[e] * pf_c[k][e] + cc[e]);
+            for (int e = 0; e < 4; ++e) v[e] = ca[e] * v[e] + (cb[e] * pf.c[k][e] + cc[e]);
             if (RES) {
-              if (RES == 2) v += 0.25f * pf_r[k];
-              else v += pf_r[k];
+              if (RES == 2) v += 0.25f * pf.r[k];
+              else v += pf.r[k];
               // the band's own rows (not the halo) of this block's channel slice leave as the block input gradient
               const int row = d_row(k);
               if (row >= 1 && row <= TH && (unsigned)(ch - c0) < 16u) *reinterpret_cast<floatx4*>(a.dy_out + doff + d_goff(k)) = v;
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(512, 1) void conv_bwd_split_pc_kernel(ConvBwdFusedA
         const int ch = (ts & 3) * 4;
         const floatx4 sc = *reinterpret_cast<const floatx4*>(s_co + ch);
         const floatx4 sh = *reinterpret_cast<const floatx4*>(s_co + 16 + ch);
-        floatx4 v = pf_x[k];
+        floatx4 v = pf.x[k];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);
         uintx2 h, m, l;
@@ -234,21 +239,27 @@ __global__ __launch_bounds__(512, 1) void conv_bwd_split_pc_kernel(ConvBwdFusedA
         *reinterpret_cast<uintx2*>(dst + 2 * XPLANE) = l;
       }
     };
-    // first band into set 0, second band into the registers
+    // first band into set 0; bands two and three into the registers
     if (t0 < total_tiles) {
-      load_band(t0);
-      write_band(t0, smem_b);
-      if (t0 + gpz < total_tiles) load_band(t0 + gpz);
+      load_band(t0, pfa);
+      if (t0 + gpz < total_tiles) load_band(t0 + gpz, pfb);
+      write_band(t0, smem_b, pfa);
+      if (t0 + 2 * gpz < total_tiles) load_band(t0 + 2 * gpz, pfa);
     }
     __syncthreads();   // set 0 is staged
-    int set = 0;
-    for (int t = t0; t < total_tiles; t += gpz) {
+    // iteration on band t: stage band t + 1 (requested two iterations ago) into the other set, request band t + 3
+    for (int t = t0; t < total_tiles; t += 2 * gpz) {
       if (t + gpz < total_tiles) {
-        write_band(t + gpz, smem_b + (set ^ 1) * SET);
-        if (t + 2 * gpz < total_tiles) load_band(t + 2 * gpz);
+        write_band(t + gpz, smem_b + SET, pfb);
+        if (t + 3 * gpz < total_tiles) load_band(t + 3 * gpz, pfb);
       }
-      __syncthreads();   // the matrix waves are done with `set`, set ^ 1 is staged
-      set ^= 1;
+      __syncthreads();   // the matrix waves are done with set 0, set 1 is staged
+      if (t + gpz >= total_tiles) break;
+      if (t + 2 * gpz < total_tiles) {
+        write_band(t + 2 * gpz, smem_b, pfa);
+        if (t + 4 * gpz < total_tiles) load_band(t + 4 * gpz, pfa);
+      }
+      __syncthreads();   // the matrix waves are done with set 1, set 0 is staged
     }
   } else if (wave < 2) {
     // ================= data gradient: M = pixels, N = the block's input channels, K = taps x C =============
@@ -290,34 +301,43 @@ __global__ __launch_bounds__(512, 1) void conv_bwd_split_pc_kernel(ConvBwdFusedA
           cur_xv[i] = *reinterpret_cast<const floatx4*>(a.x + obase + (long long)((rw * PD + grp * PG + i) * 16) * C + lane_o);
           acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
         }
-        // Walk (K step, pixel tile); the operand reads of the next unit are in flight while the six MFMAs of this one run.
-        constexpr int UNITS = KS * PG;
-        uintx4 ah[2], am[2], al[2], wl[2];
-        auto read_unit = [&](int u, int buf) {
-          const int ks = u / PG, i = u % PG;
-          const unsigned char* p = s_grp + tile_off(i) + kvar(ks) + kconst(ks);
-          ah[buf] = *reinterpret_cast<const uintx4*>(p);
-          am[buf] = *reinterpret_cast<const uintx4*>(p + PLANE);
-          al[buf] = *reinterpret_cast<const uintx4*>(p + 2 * PLANE);
-          if (i == 0) wl[ks & 1] = s_wl[ks * 64 + lane];
-        };
-        read_unit(0, 0);
+        // Walk the K steps; the operand reads of the next step are in flight while the twelve MFMAs of this
+        // one run. The two pixel tiles alternate: with one matrix wave per SIMD an MFMA that accumulates into
+        // the previous MFMA's result would wait for it.
+        static_assert(PG == 2, "two accumulators alternate");
+        uintx4 ah[2][PG], am[2][PG], al[2][PG], wl[2];
+        auto read_step = [&](int ks, int buf) {
 #pragma unroll
-        for (int u = 0; u < UNITS; ++u) {
-          const int ks = u / PG, i = u % PG, b = u & 1;
-          if (u + 1 < UNITS) read_unit(u + 1, b ^ 1);
+          for (int i = 0; i < PG; ++i) {
+            const unsigned char* p = s_grp + tile_off(i) + kvar(ks) + kconst(ks);
+            ah[buf][i] = *reinterpret_cast<const uintx4*>(p);
+            am[buf][i] = *reinterpret_cast<const uintx4*>(p + PLANE);
+            al[buf][i] = *reinterpret_cast<const uintx4*>(p + 2 * PLANE);
+          }
+          wl[buf] = s_wl[ks * 64 + lane];
+        };
+        read_step(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int b = ks & 1;
+          if (ks + 1 < KS) read_step(ks + 1, b ^ 1);
           __builtin_amdgcn_sched_barrier(0);
           const bf16x8 whv = __builtin_bit_cast(bf16x8, wh[ks]);
           const bf16x8 wmv = __builtin_bit_cast(bf16x8, wm[ks]);
-          const bf16x8 wlv = __builtin_bit_cast(bf16x8, wl[ks & 1]);
-          const bf16x8 ahv = __builtin_bit_cast(bf16x8, ah[b]), amv = __builtin_bit_cast(bf16x8, am[b]), alv = __builtin_bit_cast(bf16x8, al[b]);
+          const bf16x8 wlv = __builtin_bit_cast(bf16x8, wl[b]);
           // small terms first, then the large ones
-          acc[i] = DTF_MFMA_BF16(wlv, ahv, acc[i]);
-          acc[i] = DTF_MFMA_BF16(whv, alv, acc[i]);
-          acc[i] = DTF_MFMA_BF16(wmv, amv, acc[i]);
-          acc[i] = DTF_MFMA_BF16(wmv, ahv, acc[i]);
-          acc[i] = DTF_MFMA_BF16(whv, amv, acc[i]);
-          acc[i] = DTF_MFMA_BF16(whv, ahv, acc[i]);
+#pragma unroll
+          for (int i = 0; i < PG; ++i) acc[i] = DTF_MFMA_BF16(wlv, __builtin_bit_cast(bf16x8, ah[b][i]), acc[i]);
+#pragma unroll
+          for (int i = 0; i < PG; ++i) acc[i] = DTF_MFMA_BF16(whv, __builtin_bit_cast(bf16x8, al[b][i]), acc[i]);
+#pragma unroll
+          for (int i = 0; i < PG; ++i) acc[i] = DTF_MFMA_BF16(wmv, __builtin_bit_cast(bf16x8, am[b][i]), acc[i]);
+#pragma unroll
+          for (int i = 0; i < PG; ++i) acc[i] = DTF_MFMA_BF16(wmv, __builtin_bit_cast(bf16x8, ah[b][i]), acc[i]);
+#pragma unroll
+          for (int i = 0; i < PG; ++i) acc[i] = DTF_MFMA_BF16(whv, __builtin_bit_cast(bf16x8, am[b][i]), acc[i]);
+#pragma unroll
+          for (int i = 0; i < PG; ++i) acc[i] = DTF_MFMA_BF16(whv, __builtin_bit_cast(bf16x8, ah[b][i]), acc[i]);
           __builtin_amdgcn_sched_barrier(0);
         }
         // epilogue: ReLU mask and x-hat from the raw x, statistics, 16-byte stores
@@ -359,9 +379,13 @@ __global__ __launch_bounds__(512, 1) void conv_bwd_split_pc_kernel(ConvBwdFusedA
       const unsigned char* s_dy = smem_b + set * SET;
       const unsigned char* s_x = s_dy + 3 * PLANE;
       constexpr int MYSTEPS = G::WSTEPS / WX;
-      constexpr int WUNITS = MYSTEPS * 9 * CPW;
-      uintx2 xa[3][2];        // A: relu(bn(x)) parts of the current step
-      uintx2 db[2][3][2];     // B: dy parts of the current / next (step, tap, channel tile)
+      // A unit is one (step, tap, channel tile): six MFMAs into one accumulator. Two units run interleaved
+      // (two accumulators alternate, see the data gradient); the reads of the next pair are in flight meanwhile.
+      constexpr int UPS = 9 * CPW;                 // units per step
+      constexpr int WUNITS = MYSTEPS * UPS;
+      constexpr int WPAIRS = (WUNITS + 1) / 2;
+      uintx2 xa[2][3][2];     // A: relu(bn(x)) parts of the current / next step
+      uintx2 db[2][2][3][2];  // B: dy parts of the current / next pair of units
       // the band's sum in accumulators of its own, added to the running total once (conv_bwd_split.hip)
       floatx4 accb[CPW][9];
 #pragma unroll
@@ -372,12 +396,12 @@ __global__ __launch_bounds__(512, 1) void conv_bwd_split_pc_kernel(ConvBwdFusedA
         const unsigned char* p = s_x + lane_xa + (wx + ms * WX) * 32 * XPB;
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
-          xa[part][0] = lds_read_tr(p + part * XPLANE);
-          xa[part][1] = lds_read_tr(p + part * XPLANE + 16 * XPB);
+          xa[ms & 1][part][0] = lds_read_tr(p + part * XPLANE);
+          xa[ms & 1][part][1] = lds_read_tr(p + part * XPLANE + 16 * XPB);
         }
       };
-      auto read_b = [&](int u, int buf) {
-        const int cp = u % CPW, tap = (u / CPW) % 9, ms = u / (9 * CPW);
+      auto read_b = [&](int u, int buf, int slot) {
+        const int cp = u % CPW, tap = (u / CPW) % 9, ms = u / UPS;
         const int kh = tap / 3, kw = tap % 3;
         // dy[pixel - (tap - 1)]: halo position (row + 2 - kh, col + 2 - kw); a step is 32 / TW whole rows
         constexpr int SROWS = 32 / TW > 0 ? 32 / TW : 1;
@@ -385,27 +409,43 @@ __global__ __launch_bounds__(512, 1) void conv_bwd_split_pc_kernel(ConvBwdFusedA
         const unsigned char* p1 = p0 + (TW == 32 ? 16 * PSB : (16 / TW) * ROWB);
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
-          db[buf][part][0] = lds_read_tr(p0 + part * PLANE);
-          db[buf][part][1] = lds_read_tr(p1 + part * PLANE);
+          db[buf][slot][part][0] = lds_read_tr(p0 + part * PLANE);
+          db[buf][slot][part][1] = lds_read_tr(p1 + part * PLANE);
         }
       };
-      read_a(0);
-      read_b(0, 0);
+      auto read_pair = [&](int pr, int buf) {
+        read_b(2 * pr, buf, 0);
+        if (2 * pr + 1 < WUNITS) read_b(2 * pr + 1, buf, 1);
+        // the first unit of a step brings the step's A fragments along
+        if ((2 * pr) % UPS == 0) read_a((2 * pr) / UPS);
+        else if ((2 * pr + 1) % UPS == 0 && 2 * pr + 1 < WUNITS) read_a((2 * pr + 1) / UPS);
+      };
+      read_pair(0, 0);
 #pragma unroll
-      for (int u = 0; u < WUNITS; ++u) {
-        const int cp = u % CPW, tap = (u / CPW) % 9, b = u & 1;
-        if (u + 1 < WUNITS) read_b(u + 1, b ^ 1);
+      for (int pr = 0; pr < WPAIRS; ++pr) {
+        const int b = pr & 1;
+        if (pr + 1 < WPAIRS) read_pair(pr + 1, b ^ 1);
         __builtin_amdgcn_sched_barrier(0);
-        const bf16x8 xh = frag8(xa[0][0], xa[0][1]), xm = frag8(xa[1][0], xa[1][1]), xl = frag8(xa[2][0], xa[2][1]);
-        const bf16x8 dh = frag8(db[b][0][0], db[b][0][1]), dm = frag8(db[b][1][0], db[b][1][1]), dl = frag8(db[b][2][0], db[b][2][1]);
-        accb[cp][tap] = DTF_MFMA_BF16(xl, dh, accb[cp][tap]);
-        accb[cp][tap] = DTF_MFMA_BF16(xh, dl, accb[cp][tap]);
-        accb[cp][tap] = DTF_MFMA_BF16(xm, dm, accb[cp][tap]);
-        accb[cp][tap] = DTF_MFMA_BF16(xm, dh, accb[cp][tap]);
-        accb[cp][tap] = DTF_MFMA_BF16(xh, dm, accb[cp][tap]);
-        accb[cp][tap] = DTF_MFMA_BF16(xh, dh, accb[cp][tap]);
+        const int u0 = 2 * pr, u1 = 2 * pr + 1;
+        const bool two = u1 < WUNITS;
+        const int cp0 = u0 % CPW, tap0 = (u0 / CPW) % 9, ms0 = u0 / UPS;
+        const int cp1 = u1 % CPW, tap1 = (u1 / CPW) % 9, ms1 = two ? u1 / UPS : ms0;
+        bf16x8 x0[3], x1[3], d0[3], d1v[3];
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+          x0[part] = frag8(xa[ms0 & 1][part][0], xa[ms0 & 1][part][1]);
+          x1[part] = frag8(xa[ms1 & 1][part][0], xa[ms1 & 1][part][1]);
+          d0[part] = frag8(db[b][0][part][0], db[b][0][part][1]);
+          d1v[part] = frag8(db[b][1][part][0], db[b][1][part][1]);
+        }
+        // (x part, dy part) of the six partial products, small terms first
+        constexpr int XP[6] = {2, 0, 1, 1, 0, 0}, DP[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          accb[cp0][tap0] = DTF_MFMA_BF16(x0[XP[k]], d0[DP[k]], accb[cp0][tap0]);
+          if (two) accb[cp1][tap1] = DTF_MFMA_BF16(x1[XP[k]], d1v[DP[k]], accb[cp1][tap1]);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        if (cp == CPW - 1 && tap == 8 && u + 1 < WUNITS) read_a(u / (9 * CPW) + 1);
       }
 #pragma unroll
       for (int cp = 0; cp < CPW; ++cp)
@@ -476,18 +516,28 @@ size_t launch_bpc(const ConvBwdFusedArgs& a, hipStream_t stream, int* copies) {
 
 bool conv_bwd_split_pc_supported(int B, int H, int W, int C) {
   (void)B;
-  return H == 8 && W == 8 && C == 64;
+  return H == W && H % 8 == 0 && ((C == 16 && W == 32) || (C == 32 && W == 16) || (C == 64 && W == 8));
 }
 
 size_t conv_bwd_split_pc(const ConvBwdFusedArgs& a, hipStream_t stream, int* copies) {
   if (!conv_bwd_split_pc_supported(a.B, a.H, a.W, a.C)) throw std::runtime_error("conv_bwd_split_pc: unsupported shape");
   if (a.dy_x) {
     if (a.dy_res) {
-      if (a.dy_res_mode == 1) throw std::runtime_error("conv_bwd_split: no option-A shortcut behind a 64-channel stage");
+      if (a.dy_res_mode == 1) {
+        if (a.C == 16) return launch_bpc<16, 32, 8, true, 2>(a, stream, copies);
+        if (a.C == 32) return launch_bpc<32, 16, 8, true, 2>(a, stream, copies);
+        throw std::runtime_error("conv_bwd_split: no option-A shortcut behind a 64-channel stage");
+      }
+      if (a.C == 16) return launch_bpc<16, 32, 8, true, 1>(a, stream, copies);
+      if (a.C == 32) return launch_bpc<32, 16, 8, true, 1>(a, stream, copies);
       return launch_bpc<64, 8, 8, true, 1>(a, stream, copies);
     }
+    if (a.C == 16) return launch_bpc<16, 32, 8, true>(a, stream, copies);
+    if (a.C == 32) return launch_bpc<32, 16, 8, true>(a, stream, copies);
     return launch_bpc<64, 8, 8, true>(a, stream, copies);
   }
+  if (a.C == 16) return launch_bpc<16, 32, 8, false>(a, stream, copies);
+  if (a.C == 32) return launch_bpc<32, 16, 8, false>(a, stream, copies);
   return launch_bpc<64, 8, 8, false>(a, stream, copies);
 }
 
