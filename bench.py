@@ -237,6 +237,9 @@ def main() -> None:
                          "stride-1 ResNet layers (forward, and the fused backward kernels of the 16- and 32-channel stages) on the bf16 "
                          "matrix pipe, both operands split into three bf16 values, six partial products per product, fp32 accumulation (error against fp64 next to the exact "
                          "path's: profiles/r3_split_error_table.txt)")
+    ap.add_argument("--no-second-line", action="store_true",
+                    help="one-GPU ResNet runs with --matmul fp32 also time the bf16x6 path afterwards and report it as "
+                         "\"second_line\" inside the JSON object (never as the headline value); this flag leaves that out")
     ap.add_argument("--batch", type=int, default=1024,
                     help="per-GPU batch (weak scaling). 1024 is sized for the MI355X (activations + gradients of ResNet-20 "
                          "take ~1.5 GB of the 288 GB HBM and each layer launches >=2 workgroups per CU); the reference's "
@@ -316,122 +319,151 @@ def main() -> None:
 
         args.buckets = default_grad_buckets(sum(sp.numel for sp in (lenet_param_specs() if lenet else resnet_param_specs(n))))
 
-    stream = torch.cuda.Stream()
-    with torch.cuda.stream(stream):
-        if lenet:
-            from distributed_tensorflow_amd.models.lenet_hip import LeNetHipStep
-
-            step = LeNetHipStep(args.batch, optimizer=args.optimizer, num_buckets=args.buckets if multi else 1)
-        else:
-            from distributed_tensorflow_amd.models.resnet_hip import ResNetHipStep
-
-            step = ResNetHipStep(n, args.batch, optimizer=args.optimizer, num_buckets=args.buckets if multi else 1, matmul=args.matmul)
-        mark("step program recorded: %d kernels, %d segment(s)" % (step.kernel_count, step.num_segments))
-        # identical initial parameters on every replica
-        comm.broadcast(step.arena.params, 0)
-        if multi:
-            mark("parameters broadcast (first collective done)")
-        if args.allreduce == "p2p":
-            comm.enable_p2p(step.arena.grads_full.numel())
-            mark("peer handles imported (p2p all-reduce buffers mapped)")
-        hw, ch = (28, 1) if lenet else (32, 3)
-        images = torch.randn(args.batch, hw, hw, ch, device=comm.device)
-        labels = torch.randint(0, 10, (args.batch,), device=comm.device)
-        step.load_batch(images, labels)
-        batcher = None
-        if args.input == "gpu_batcher":
-            import numpy as np
-
-            rs = np.random.RandomState(99 + comm.rank)
+    def run_path(matmul: str) -> dict:
+        """Builds the step program for one matrix path and times it: warm-up, then exactly --steps steps
+        between barrier + synchronize on both sides."""
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
             if lenet:
-                from distributed_tensorflow_amd.data import mnist as mnist_data
+                from distributed_tensorflow_amd.models.lenet_hip import LeNetHipStep
 
-                # MNIST-shaped synthetic training set (60000 x 28 x 28 x 1 in [-0.5, 0.5], int64 labels), resident in HBM
-                ds = mnist_data.DataSet(rs.uniform(-0.5, 0.5, size=(60000, 28, 28, 1)).astype(np.float32),
-                                        rs.randint(0, 10, size=60000).astype(np.int64))
-                batcher = mnist_data.GpuBatcher(ds, comm.device)
+                step = LeNetHipStep(args.batch, optimizer=args.optimizer, num_buckets=args.buckets if multi else 1)
             else:
-                from distributed_tensorflow_amd.data import cifar10 as cifar_data
+                from distributed_tensorflow_amd.models.resnet_hip import ResNetHipStep
 
-                # CIFAR-shaped synthetic training set, zero-padded by 2 like prepare_train_data's (50000 x 36 x 36 x 3)
-                data = np.zeros((50000, 36, 36, 3), dtype=np.float32)
-                data[:, 2:34, 2:34, :] = rs.randint(0, 256, size=(50000, 32, 32, 3)).astype(np.float32)
-                batcher = cifar_data.GpuTrainBatcher(data, rs.randint(0, 10, size=50000), 2, 7 + comm.rank, comm.device)
-                del data
-            mark("synthetic data set resident in HBM")
-        mode = "off" if args.no_graph else args.graph
-        graph = (mode == "on") or (mode == "auto" and not getattr(step, "side_stream", False))
-        if graph:
-            step.instantiate(per_segment=multi)
-            mark("hipGraph instantiated")
-        nseg = step.num_segments
-        ranges = step.bucket_ranges
-        grads = step.arena.grads
-        t_global = 0
-        # events around the collectives of a step (N > 1): their share of the step says where a scaling loss comes from
-        coll_events = []
+                step = ResNetHipStep(n, args.batch, optimizer=args.optimizer, num_buckets=args.buckets if multi else 1, matmul=matmul)
+            mark("step program recorded: %d kernels, %d segment(s)" % (step.kernel_count, step.num_segments))
+            # identical initial parameters on every replica
+            comm.broadcast(step.arena.params, 0)
+            if multi:
+                mark("parameters broadcast (first collective done)")
+            if args.allreduce == "p2p":
+                comm.enable_p2p(step.arena.grads_full.numel())
+                mark("peer handles imported (p2p all-reduce buffers mapped)")
+            hw, ch = (28, 1) if lenet else (32, 3)
+            images = torch.randn(args.batch, hw, hw, ch, device=comm.device)
+            labels = torch.randint(0, 10, (args.batch,), device=comm.device)
+            step.load_batch(images, labels)
+            batcher = None
+            if args.input == "gpu_batcher":
+                import numpy as np
 
-        def one_step(timed: bool = False) -> None:
-            nonlocal t_global
-            t_global += 1
-            if batcher is not None:
-                batcher.next_batch_into(step.images, step.labels)
-            step.set_hyper(lr_t=ref.adam_lr_t(args.lr, t_global) if args.optimizer == "adam" else args.lr,
-                           grad_scale=1.0 / world, momentum=0.9, weight_decay=2e-4, step=t_global if lenet else None)
-            if not multi:
-                step.run(-1, graph)
-                return
-            for i in range(nseg - 1):
-                step.run(i, graph)
-                lo, hi = ranges[i]
-                if i < nseg - 2:
-                    comm.all_reduce_async(grads[lo:hi])   # overlaps the rest of backward
+                rs = np.random.RandomState(99 + comm.rank)
+                if lenet:
+                    from distributed_tensorflow_amd.data import mnist as mnist_data
+
+                    # MNIST-shaped synthetic training set (60000 x 28 x 28 x 1 in [-0.5, 0.5], int64 labels), resident in HBM
+                    ds = mnist_data.DataSet(rs.uniform(-0.5, 0.5, size=(60000, 28, 28, 1)).astype(np.float32),
+                                            rs.randint(0, 10, size=60000).astype(np.int64))
+                    batcher = mnist_data.GpuBatcher(ds, comm.device)
                 else:
-                    # nothing left to overlap with: issued on the compute stream, so two events bracket exactly
-                    # the part of the step that is exposed communication
-                    if timed:
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record(stream)
-                    comm.all_reduce_inline(grads[lo:hi])
-                    if timed:
-                        e1.record(stream)
-                        coll_events.append((e0, e1))
-            comm.wait_all()
-            step.run(nseg - 1, graph)
+                    from distributed_tensorflow_amd.data import cifar10 as cifar_data
 
-        for w in range(args.warmup):
-            one_step()
-            if w == 0:
-                stream.synchronize()
-                mark("first step done" + (" (with its gradient all-reduce)" if multi else ""))
-        stream.synchronize()
-        comm.barrier()
-        torch.cuda.synchronize()
-        mark("warm-up done, timing %d steps" % args.steps)
-        # one event per step boundary (recorded on the step's stream, never waited on inside the
-        # timed region) gives the per-step GPU times for the p50
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-        t0 = time.perf_counter()
-        marks[0].record(stream)
-        for i in range(args.steps):
-            one_step(timed=True)
-            marks[i + 1].record(stream)
-        stream.synchronize()
-        torch.cuda.synchronize()
-        comm.barrier()
-        dt = time.perf_counter() - t0
-        loss = step.loss_value()
-        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-        p50 = per_step[len(per_step) // 2] if per_step else float("nan")
-        coll_ms = sum(e0.elapsed_time(e1) for e0, e1 in coll_events) / max(1, args.steps)
-        mark("timed region done")
+                    # CIFAR-shaped synthetic training set, zero-padded by 2 like prepare_train_data's (50000 x 36 x 36 x 3)
+                    data = np.zeros((50000, 36, 36, 3), dtype=np.float32)
+                    data[:, 2:34, 2:34, :] = rs.randint(0, 256, size=(50000, 32, 32, 3)).astype(np.float32)
+                    batcher = cifar_data.GpuTrainBatcher(data, rs.randint(0, 10, size=50000), 2, 7 + comm.rank, comm.device)
+                    del data
+                mark("synthetic data set resident in HBM")
+            mode = "off" if args.no_graph else args.graph
+            graph = (mode == "on") or (mode == "auto" and not getattr(step, "side_stream", False))
+            if graph:
+                step.instantiate(per_segment=multi)
+                mark("hipGraph instantiated")
+            nseg = step.num_segments
+            ranges = step.bucket_ranges
+            grads = step.arena.grads
+            t_global = 0
+            # events around the collectives of a step (N > 1): their share of the step says where a scaling loss comes from
+            coll_events = []
 
-    t = torch.tensor([dt], device=comm.device, dtype=torch.float64)
-    if multi:
-        import torch.distributed as dist
+            def one_step(timed: bool = False) -> None:
+                nonlocal t_global
+                t_global += 1
+                if batcher is not None:
+                    batcher.next_batch_into(step.images, step.labels)
+                step.set_hyper(lr_t=ref.adam_lr_t(args.lr, t_global) if args.optimizer == "adam" else args.lr,
+                               grad_scale=1.0 / world, momentum=0.9, weight_decay=2e-4, step=t_global if lenet else None)
+                if not multi:
+                    step.run(-1, graph)
+                    return
+                for i in range(nseg - 1):
+                    step.run(i, graph)
+                    lo, hi = ranges[i]
+                    if i < nseg - 2:
+                        comm.all_reduce_async(grads[lo:hi])   # overlaps the rest of backward
+                    else:
+                        # nothing left to overlap with: issued on the compute stream, so two events bracket exactly
+                        # the part of the step that is exposed communication
+                        if timed:
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record(stream)
+                        comm.all_reduce_inline(grads[lo:hi])
+                        if timed:
+                            e1.record(stream)
+                            coll_events.append((e0, e1))
+                comm.wait_all()
+                step.run(nseg - 1, graph)
 
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+            for w in range(args.warmup):
+                one_step()
+                if w == 0:
+                    stream.synchronize()
+                    mark("first step done" + (" (with its gradient all-reduce)" if multi else ""))
+            stream.synchronize()
+            comm.barrier()
+            torch.cuda.synchronize()
+            mark("warm-up done, timing %d steps" % args.steps)
+            # one event per step boundary (recorded on the step's stream, never waited on inside the
+            # timed region) gives the per-step GPU times for the p50
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+            t0 = time.perf_counter()
+            marks[0].record(stream)
+            for i in range(args.steps):
+                one_step(timed=True)
+                marks[i + 1].record(stream)
+            stream.synchronize()
+            torch.cuda.synchronize()
+            comm.barrier()
+            dt = time.perf_counter() - t0
+            loss = step.loss_value()
+            per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+            p50 = per_step[len(per_step) // 2] if per_step else float("nan")
+            coll_ms = sum(e0.elapsed_time(e1) for e0, e1 in coll_events) / max(1, args.steps)
+            mark("timed region done")
+        return dict(dt=dt, p50=p50, loss=loss, coll_ms=coll_ms, graph=graph, buckets=len(ranges), kernels=step.kernel_count,
+                    deterministic=bool(getattr(step, "deterministic", False)),
+                    split=(len(getattr(step, "_split_fwd", ())), len(getattr(step, "_split_bwd", ()))))
+
+    def max_over_ranks(dt: float) -> float:
+        t = torch.tensor([dt], device=comm.device, dtype=torch.float64)
+        if multi:
+            import torch.distributed as dist
+
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def matmul_label(matmul: str, split) -> str:
+        if matmul == "fp32" or lenet:
+            return "fp32 (v_mfma_f32_16x16x4_f32)"
+        return ("bf16x6 split, fp32 accumulate (stride-1 layers: %d forward and %d fused backward kernels; everything else "
+                "fp32 MFMA)" % split)
+
+    res = run_path(args.matmul)
+    dt = max_over_ranks(res["dt"])
+    # Second, separately labelled line inside the same JSON object (one GPU only, never the headline value):
+    # the opt-in split-operand path on the same model, batch, steps and warm-up.
+    second = None
+    if not lenet and args.matmul == "fp32" and world == 1 and not args.rehearse_collectives and not args.no_second_line:
+        try:
+            r2 = run_path("bf16x6")
+            second = {"matmul": matmul_label("bf16x6", r2["split"]), "value": round(args.batch * args.steps / r2["dt"], 1),
+                      "unit": "images/sec", "ms_per_step": round(r2["dt"] / args.steps * 1e3, 4), "p50_ms_per_step": round(r2["p50"], 4),
+                      "final_loss": round(r2["loss"], 4), "kernels_per_step": r2["kernels"],
+                      "error_table": "profiles/r3_split_error_table.txt (max error vs fp64 <= 1.33 x the exact path's)"}
+        except Exception as e:   # noqa: BLE001 - the headline line must not depend on the opt-in path
+            second = {"matmul": "bf16x6", "error": "%s: %s" % (type(e).__name__, e)}
+    loss, p50, coll_ms, graph = res["loss"], res["p50"], res["coll_ms"], res["graph"]
     if comm.is_chief:
         ms = dt / args.steps * 1e3
         value = args.batch * world * args.steps / dt
@@ -453,21 +485,21 @@ def main() -> None:
             "scaling": "weak",
             "vs_baseline": round(value / floor, 2) if floor else None,
             "dtype": "fp32",
-            "matmul": "fp32 (v_mfma_f32_16x16x4_f32)" if args.matmul == "fp32" or lenet else
-                      "bf16x6 split, fp32 accumulate (stride-1 layers: %d forward and %d fused backward kernels; everything else fp32 MFMA)" % (len(step._split_fwd), len(step._split_bwd)),
+            "matmul": matmul_label(args.matmul, res["split"]),
             "data": "synthetic %s-shaped images, random-init weights" % ("MNIST" if lenet else "CIFAR-10"),
             "input": args.input,
             "config": {
                 "model": args.model, "global_batch": args.batch * world, "per_gpu_batch": args.batch,
                 "reference_worker_batch": 128 if lenet else 256, "seq_len": None, "image": "28x28x1" if lenet else "32x32x3",
                 "optimizer": args.optimizer, "parallelism": f"dp{world}", "hip_graph": graph,
-                "deterministic": bool(getattr(step, "deterministic", False)),
+                "deterministic": res["deterministic"],
                 "exposed_allreduce_ms_per_step": round(coll_ms, 4) if multi else None,
-                "allreduce": ("p2p" if comm.p2p is not None else topo["backend"]) if multi else "none", "grad_buckets": len(ranges),
-                "kernels_per_step": step.kernel_count, "final_loss": round(loss, 4),
+                "allreduce": ("p2p" if comm.p2p is not None else topo["backend"]) if multi else "none", "grad_buckets": res["buckets"],
+                "kernels_per_step": res["kernels"], "final_loss": round(loss, 4),
                 "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
                 "baseline": "CPU reference floor (bench/cpu_floor.json); the reference publishes no numbers",
             },
+            "second_line": second,
         }))
     comm.close()
 
