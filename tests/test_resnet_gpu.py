@@ -276,15 +276,18 @@ def test_queued_steps_keep_their_own_scalars():
     assert torch.equal(synced, queued)
 
 
+@pytest.mark.parametrize("matmul", ["fp32", "bf16x6"])
 @pytest.mark.parametrize("n,batch,num_buckets", [(1, 64, 1), (1, 256, 3), (3, 128, 1)])
-def test_training_is_reproducible_bit_for_bit(n, batch, num_buckets):
+def test_training_is_reproducible_bit_for_bit(n, batch, num_buckets, matmul):
     """Two runs of 24 training steps from the same state end with identical parameters, optimizer
     slots and loss-carrying gradients: no float atomics in arrival order anywhere in the step
     (filter gradients: one copy per workgroup, added in a fixed order; statistics: exact fp64
     accumulation on a grid; classifier gradients: fixed-order in-block sums)."""
     def run():
-        step, _, _ = _make(n, batch, num_buckets=num_buckets)
+        step, _, _ = _make(n, batch, num_buckets=num_buckets, matmul=matmul)
         assert step.deterministic
+        if matmul == "bf16x6":
+            assert step._split_fwd and step._split_bwd   # both split-operand kernel families are in the step
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
             step.instantiate(per_segment=True)
