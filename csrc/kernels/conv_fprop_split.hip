@@ -277,9 +277,10 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_split_kernel(ConvFpropArgs 
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp) wq[d][sp] = wfrag(d, sp);
     }
-    if (t + gpz < total_tiles) load_tile(t + gpz);   // in flight during the MFMA phase
-    // epilogue operands of THIS tile (residual / mask source / extra gradient): requested here, used
-    // after the MFMA phase (the filter fragments already take the registers a tile-ahead prefetch would need)
+    // epilogue operands of THIS tile (residual / mask source / extra gradient): used after the MFMA phase
+    // (the filter fragments already take the registers a tile-ahead prefetch would need). They are
+    // requested BEFORE the next tile: vector memory operations retire in order, so waiting for a load
+    // issued behind the prefetch would wait for the whole prefetch - a memory round trip per tile.
     floatx4 cur_rv[P], cur_xv[BWD ? P : 1];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
@@ -291,6 +292,8 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_split_kernel(ConvFpropArgs 
         if (a.extra) cur_rv[i] = *reinterpret_cast<const floatx4*>(a.extra + oo);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + gpz < total_tiles) load_tile(t + gpz);   // in flight during the MFMA phase
 
     floatx4 acc[P];
 #pragma unroll
