@@ -114,7 +114,7 @@ PYBIND11_MODULE(_hip, m) {
     V(B); V(H); V(W); V(C);
     P(dy_x, const float); a.dy_bn = as_bn(d, "dy_bn"); P(dy_gsums, const double); P(dy_dgamma, float); P(dy_dbeta, float);
     P(dy_res, const float); P(dy_out, float); V(dy_res_mode);
-    P(tile_counters, int);
+    P(tile_counters, int); P(dbg_stamps, unsigned long long);
     const bool split = d.contains("split") && d["split"].cast<bool>();   // wpk_t holds the split-operand packing
     return split ? conv_bwd_split(a, as_stream(stream)) : conv_bwd_fused(a, as_stream(stream));
   });

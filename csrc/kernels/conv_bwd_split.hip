@@ -308,17 +308,29 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_split_kernel(ConvBwdFusedArgs
   // The persistent band loop, once per role: stage, barrier, request the next band, the role's MFMA phase, barrier.
   auto band_loop = [&](auto&& phase) __attribute__((always_inline)) {
     int t_next = t + gpz;
+    int band_no = 0;
+    unsigned long long* stamps = a.dbg_stamps ? a.dbg_stamps + ((size_t)blockIdx.x * 4 + wave) * 48 : nullptr;
+    auto stamp = [&](int k) {   // timing experiments only (bench/diag/split_bwd_timeline.py)
+      if (stamps && lane == 0 && band_no < 8) stamps[band_no * 6 + k] = wall_clock64();
+    };
     while (t < total_tiles) {
       const int n = t / bands;
       const int oy0 = (t - n * bands) * TH;
+      stamp(0);
       write_band(((long long)(n * a.H + oy0 - 1) * a.W) * C);
+      stamp(1);
       __syncthreads();
+      stamp(2);
       if (t_next < total_tiles) {   // in flight during the MFMA phase
         load_band(t_next);
         if (RES) load_res(t_next);
       }
+      stamp(3);
       phase(((long long)(n * a.H + oy0) * TW) * C);
+      stamp(4);
       __syncthreads();   // all waves are done with this band's planes
+      stamp(5);
+      ++band_no;
       t = t_next;
       t_next += gpz;
     }

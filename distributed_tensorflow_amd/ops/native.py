@@ -550,7 +550,7 @@ def conv_bwd_fused_supported(x: torch.Tensor) -> bool:
 
 def conv_bwd_fused(dy, x, bn: BnState, wpk_t, dw, gsums, *, slot_stride: int = 0, extra=None, out=None,
                    dy_bn=None, dy_dgamma=None, dy_dbeta=None, dy_res=None, dy_out=None, dy_res_option_a=False,
-                   tile_counters=None, parts: Optional[GradientParts] = None, split: bool = False):
+                   tile_counters=None, parts: Optional[GradientParts] = None, split: bool = False, dbg_stamps=None):
     """Backward of y = conv3x3(relu(bn(x)), W), stride 1, in one kernel: returns the masked data
     gradient g, adds (sum g, sum g*xhat) to `gsums` and the filter gradient to `dw`
     (see csrc/kernels/conv.h: ConvBwdFusedArgs).
@@ -623,6 +623,8 @@ def conv_bwd_fused(dy, x, bn: BnState, wpk_t, dw, gsums, *, slot_stride: int = 0
         d["tile_counters"] = _chk(tile_counters, "tile_counters", torch.int32)
     if split:
         d["split"] = True
+    if dbg_stamps is not None:   # timing experiments only: int64 [blocks][4][8][6], see ConvBwdFusedArgs::dbg_stamps
+        d["dbg_stamps"] = _chk(dbg_stamps, "dbg_stamps", torch.int64)
     if parts is not None:
         d["dw_part"] = parts.add(dw, int(hip().conv_bwd_fused_copies(d)))
     hip().conv_bwd_fused(d, stream())
