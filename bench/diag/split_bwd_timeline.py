@@ -29,7 +29,7 @@ for hw, c in [(32, 16), (16, 32)]:
             stamps.zero_()
             nv.conv_bwd_fused(dy, x, bn, wpk, slots[0, :n].view(3, 3, c, c), gs, slot_stride=n, out=out, split=True, dbg_stamps=stamps, **kw)
         torch.cuda.synchronize()
-        st = stamps.view(1024, 4, 8, 6).cpu().double()
+        st = stamps.view(1024, 4, 48)[:, :, :42].reshape(1024, 4, 7, 6).cpu().double()
         used = st[:, :, :, 0] > 0
         nb = int(used[:, 0, 0].sum())
         st = st[:nb]
@@ -39,7 +39,7 @@ for hw, c in [(32, 16), (16, 32)]:
         for role, waves in (("data gradient waves", [0, 1]), ("filter gradient waves", [2, 3])):
             u = us[:, waves]
             d = [(u[..., k + 1] - u[..., k]).mean(dim=(0, 1)) for k in range(5)]
-            for band in range(8):
+            for band in range(7):
                 if float(st[:, 0, band, 0].max()) == 0:
                     break
                 print(f"   {role} band {band}: " + " | ".join(f"{float(x[band]):6.2f}" for x in d) + f"   start at {float(u[..., band, 0].mean()):7.2f}, end {float(u[..., band, 5].mean()):7.2f}")

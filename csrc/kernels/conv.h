@@ -164,8 +164,9 @@ struct ConvBwdFusedArgs {
   // neighbour process) the remaining blocks pick up the work instead of the grid waiting for the
   // slow blocks' fixed share. nullptr = static striding.
   int* tile_counters;
-  // timing experiments only (conv_bwd_split.hip): [blocks][4 waves][8 bands][6] wall-clock stamps of lane 0 -
-  // band start, staged, past the barrier, prefetch issued, MFMA phase done, past the second barrier
+  // timing experiments only (conv_bwd_split.hip): [blocks][4 waves][48]: for the first 7 bands six wall-clock
+  // stamps of lane 0 - band start, staged, past the barrier, prefetch issued, MFMA phase done, past the
+  // second barrier - then at [42], [43] the wave's HW_ID and XCC_ID registers
   unsigned long long* dbg_stamps;
   AbortRef abort;   // short-circuit reference, filled in by the launch dispatcher
 };

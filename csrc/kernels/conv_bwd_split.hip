@@ -311,8 +311,12 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_split_kernel(ConvBwdFusedArgs
     int band_no = 0;
     unsigned long long* stamps = a.dbg_stamps ? a.dbg_stamps + ((size_t)blockIdx.x * 4 + wave) * 48 : nullptr;
     auto stamp = [&](int k) {   // timing experiments only (bench/diag/split_bwd_timeline.py)
-      if (stamps && lane == 0 && band_no < 8) stamps[band_no * 6 + k] = wall_clock64();
+      if (stamps && lane == 0 && band_no < 7) stamps[band_no * 6 + k] = wall_clock64();
     };
+    if (stamps && lane == 0) {   // where the wave runs: HW_ID (wave, SIMD, CU, SE) and XCC_ID, raw (bench/diag/wg_placement.py)
+      stamps[42] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      stamps[43] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
     while (t < total_tiles) {
       const int n = t / bands;
       const int oy0 = (t - n * bands) * TH;
