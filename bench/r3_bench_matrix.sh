@@ -1,5 +1,5 @@
 #!/bin/bash
-# bench.py lines for the numbers quoted in BASELINE.md / README.md: ResNet-20 and LeNet, replayed batch and
+# bench.py lines for the numbers the documents quote: ResNet-20 and LeNet, replayed batch and
 # fresh batches through the GPU input path, at the benchmark batch and at the reference's.
 out=gpurun_out/r3_bench_matrix.jsonl
 : > $out

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Re-measures every number quoted in README.md / BASELINE.md on one GPU; results under gpurun_out/refresh/.
+# Re-measures every number the documents quote on one GPU; results under gpurun_out/refresh/.
 set -e
 cd "$(dirname "$0")/.."
 O=gpurun_out/refresh
