@@ -227,6 +227,8 @@ def define_extension_flags() -> None:
     DEFINE_string("data_dir", "", "Directory holding MNIST idx / CIFAR-10 python-batch files; empty = synthetic data")
     DEFINE_boolean("synthetic_data", False, "Use synthetic data of the dataset's shape (no files needed)")
     DEFINE_string("optimizer", "adam", "adam (the reference's choice) or momentum (momentum SGD + weight decay)")
+    DEFINE_string("matmul", "fp32", "ResNet on the GPU: fp32 = every product on the exact-fp32 matrix instruction; bf16x6 = the stride-1 "
+                  "3x3 layers on the bf16 matrix pipe with fp32 operands split three ways and fp32 accumulation (opt-in)")
     DEFINE_float("momentum", 0.9, "Momentum of the momentum-SGD optimizer")
     DEFINE_string("device", "auto", "auto, cuda or cpu")
     DEFINE_boolean("async_method", False, "Asynchronous SGD over staleness-bounded parameter shards")

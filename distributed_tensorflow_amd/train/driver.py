@@ -223,6 +223,7 @@ def train(flags, model: str) -> Dict:
         num_buckets=buckets, use_graph=flags.hip_graph,
         # kernels that return at once when the update they work for is complete (GPU replicas)
         abortable=bool(world > 1 and (flags.soft_kill_method or flags.backup_worker_method)),
+        matmul=flags.matmul,
     )
     # On the GPU the dataset lives in HBM: ResNet crops + whitens with one kernel per step, LeNet
     # slices its batches device-to-device

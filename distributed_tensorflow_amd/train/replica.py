@@ -182,7 +182,7 @@ class HipReplica(ReplicaBase):
 
     def __init__(self, model: str, batch_size: int, *, num_residual_blocks: int = 18, optimizer: str = "adam",
                  momentum: float = 0.9, weight_decay: float = 0.0, seed: int = 66478, num_buckets: int = 1,
-                 use_graph: bool = True, abortable: bool = False, inference_only: bool = False):
+                 use_graph: bool = True, abortable: bool = False, inference_only: bool = False, matmul: Optional[str] = None):
         from ..models.lenet_hip import LeNetHipStep
         from ..models.resnet_hip import ResNetHipStep
 
@@ -223,7 +223,7 @@ class HipReplica(ReplicaBase):
                     # a step whose kernels can return early keeps the atomic gradient flush: behind a
                     # short-circuited kernel the optimizer must find the zeros of the step prologue
                     self.step = ResNetHipStep(num_residual_blocks, batch_size, self.arena, optimizer=optimizer, num_buckets=num_buckets,
-                                              deterministic=False if abortable else None)
+                                              deterministic=False if abortable else None, matmul=matmul)
         finally:
             if abortable:
                 nv.hip().set_abort_ref(0, 0)
@@ -352,4 +352,5 @@ def make_replica(model: str, batch_size: int, device: str = "auto", **kw) -> Rep
     kw.pop("use_graph", None)
     kw.pop("abortable", None)
     kw.pop("inference_only", None)
+    kw.pop("matmul", None)
     return TorchReplica(model, batch_size, device="cpu", **kw)

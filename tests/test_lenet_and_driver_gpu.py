@@ -64,12 +64,13 @@ def test_lenet_dropout_training_reduces_loss_under_graph_replay():
     assert losses[1] < losses[0]
 
 
-def test_driver_trains_resnet_on_gpu_and_evaluator_scores_it(tmp_path):
+@pytest.mark.parametrize("matmul", ["fp32", "bf16x6"])
+def test_driver_trains_resnet_on_gpu_and_evaluator_scores_it(tmp_path, matmul):
     d = str(tmp_path / "train")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "DistributedResNet/src/resnet_distributed_train.py", "--synthetic_data", "--batch_size=32",
                         "--num_residual_blocks=1", "--max_steps=12", f"--train_dir={d}", "--initial_learning_rate=0.001",
-                        "--log_every=4", "--should_summarize=true", "--save_summaries_secs=0"],
+                        "--log_every=4", "--should_summarize=true", "--save_summaries_secs=0", f"--matmul={matmul}"],
                        capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     steps = [int(m.group(1)) for m in (re.match(r".*step (\d+), loss = ", l) for l in r.stderr.splitlines()) if m]
