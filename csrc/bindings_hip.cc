@@ -163,13 +163,21 @@ PYBIND11_MODULE(_hip, m) {
     V(B); V(Cin); V(Cout); V(flip); V(imgs);
     P(pool_dp, const float); P(pool_arg, const unsigned char); P(pool_p, const float);
     P(pool_out, float); P(pool_arg_out, unsigned char);
-    conv5x5_tile(a, as_stream(stream));
+    const bool split = d.contains("split") && d["split"].cast<bool>();   // w holds the split-operand packing
+    if (split) conv5x5_split(a, as_stream(stream));
+    else conv5x5_tile(a, as_stream(stream));
   });
   m.def("conv5x5_pack", [](const py::dict& d, uint64_t stream) {
     Conv5x5PackArgs a{};
     P(w, const float); P(out, float); V(Cin); V(Cout);
     conv5x5_pack(a, as_stream(stream));
   });
+  m.def("conv5x5_split_pack", [](const py::dict& d, uint64_t stream) {
+    Conv5x5PackArgs a{};
+    P(w, const float); P(out, float); V(Cin); V(Cout); V(flip);
+    conv5x5_split_pack(a, as_stream(stream));
+  });
+  m.def("conv5x5_split_packed_floats", &conv5x5_split_packed_floats);
   m.def("conv5x5_tile_supported", &conv5x5_tile_supported);
   m.def("conv5x5_wgrad", [](const py::dict& d, uint64_t stream) {
     Conv5x5WgradArgs a{};

@@ -244,7 +244,14 @@ struct Conv5x5PackArgs {
   const float* w;   // [25][Cin][Cout]
   float* out;       // [25][Cout][Cin]
   int Cin, Cout;
+  int flip;         // conv5x5_split_pack only: pack the data-gradient operand (taps reversed, channel roles swapped)
 };
+// Opt-in split-operand ("bf16x6") form of conv5x5_tile, forward and data gradient (conv5x5_split.hip):
+// `w` is then conv5x5_split_pack's output for the same direction (float-typed storage of
+// conv5x5_split_packed_floats() elements holding bf16 values), `imgs` is ignored.
+void conv5x5_split(const Conv5x5Args& a, hipStream_t stream);
+void conv5x5_split_pack(const Conv5x5PackArgs& a, hipStream_t stream);   // a.w = the HWIO filter [5,5,32,64]
+size_t conv5x5_split_packed_floats();
 // Filter gradient of that layer: dw [25][32][64] (HWIO) += sum_p x[p + tap] (x) dy[p]; with
 // slot_stride != 0 into the copy of the workgroup's XCD (dw + slot * slot_stride).
 struct Conv5x5WgradArgs {

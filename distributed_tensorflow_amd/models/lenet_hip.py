@@ -27,8 +27,16 @@ from .lenet import DROPOUT_KEEP, NUM_LABELS, SEED, lenet_param_specs
 
 class LeNetHipStep(StepProgramBase):
     def __init__(self, batch: int, arena: Optional[ParamArena] = None, *, optimizer: str = "adam", num_buckets: int = 1,
-                 training: bool = True, device: str | torch.device = "cuda", dropout: bool = True):
+                 training: bool = True, device: str | torch.device = "cuda", dropout: bool = True, matmul: Optional[str] = None):
         nv.require()
+        import os
+
+        # matmul="bf16x6" (or DTF_MATMUL): the second convolution's forward pass and data gradient run on
+        # the bf16 matrix pipe with fp32 operands split three ways and fp32 accumulation
+        # (csrc/kernels/conv5x5_split.hip); opt-in, everything else stays on the exact-fp32 instruction
+        self.matmul = matmul or os.environ.get("DTF_MATMUL", "fp32")
+        if self.matmul not in ("fp32", "bf16x6"):
+            raise ValueError("matmul must be 'fp32' or 'bf16x6'")
         self.batch, self.training, self.optimizer = batch, training, optimizer
         self.device = torch.device(device)
         self.dropout = dropout and training
@@ -41,7 +49,10 @@ class LeNetHipStep(StepProgramBase):
         f32 = dict(device=dev, dtype=torch.float32)
         self._init_common((28, 28, 1))
         a = arena
-        self.wpk2 = torch.empty(25 * 32 * 64, **f32)   # [tap][out][in], the whole-image kernel's operand
+        split = self.matmul == "bf16x6"
+        nw = int(nv.hip().conv5x5_split_packed_floats()) if split else 25 * 32 * 64
+        self.wpk2 = torch.empty(nw, **f32)   # [tap][out][in], the whole-image kernel's operand (or its split-operand packing)
+        self.wpk2_t = torch.empty(nw, **f32) if split and training else None   # data-gradient packing
         self.p1 = torch.empty((B, 14, 14, 32), **f32)
         self.arg1 = torch.empty((B, 14, 14, 32), device=dev, dtype=torch.uint8)
         self.p2 = torch.empty((B, 7, 7, 64), **f32)
@@ -66,12 +77,18 @@ class LeNetHipStep(StepProgramBase):
             # FC1 is a k-split product that accumulates into its output: cleared with everything else
             self._record_prologue(also_zero=[self.h])
             p.mark_phase("forward")
-            nv.conv5x5_pack(a.param("conv2_weights"), self.wpk2)
+            split = self.matmul == "bf16x6"
+            if split:
+                nv.conv5x5_split_pack(a.param("conv2_weights"), out=self.wpk2)
+                if self.training:
+                    nv.conv5x5_split_pack(a.param("conv2_weights"), flip=True, out=self.wpk2_t)
+            else:
+                nv.conv5x5_pack(a.param("conv2_weights"), self.wpk2)
             # ---------------- forward
             # conv1 + bias + ReLU + pool in one kernel: the 28x28x32 activation is never written
             nv.conv1_pool_fwd(self.images, a.param("conv1_weights"), a.param("conv1_biases"), out=self.p1, arg=self.arg1)
             # conv2 + bias + ReLU + pool: the 14x14x64 activation stays in LDS
-            nv.conv5x5_tile(self.p1, self.wpk2, bias=a.param("conv2_biases"), pool_out=(self.p2, self.arg2))
+            nv.conv5x5_tile(self.p1, self.wpk2, bias=a.param("conv2_biases"), pool_out=(self.p2, self.arg2), split=split)
             flat = self.p2.view(B, -1)
             # FC1's raw product; its bias, ReLU and dropout, FC2, the loss and the backward pass down
             # to FC1's pre-activation are one kernel, so the hidden activations never reach memory
@@ -117,7 +134,10 @@ class LeNetHipStep(StepProgramBase):
                     self._w2_parts = torch.empty(nv.conv5x5_wgrad_parts(B), 25 * 32 * 64, device=self.device, dtype=torch.float32)
                 nv.conv5x5_wgrad(self.p1, None, a.grad("conv2_weights"), partials=self._w2_parts, pooled=pooled2)
                 # data gradient: the same kernel over the unpacked filter, taps walked backwards
-                nv.conv5x5_tile(None, a.param("conv2_weights"), flip=True, out=self.dp1, pooled=pooled2)
+                if split:
+                    nv.conv5x5_tile(None, self.wpk2_t, flip=True, out=self.dp1, pooled=pooled2, split=True)
+                else:
+                    nv.conv5x5_tile(None, a.param("conv2_weights"), flip=True, out=self.dp1, pooled=pooled2)
                 # pool backward + ReLU mask + filter and bias gradients of conv1 in one kernel
                 nv.conv1_pool_bwd(self.images, self.dp1, self.arg1, self.p1, slot_view("conv1_weights"),
                                   slot_view("conv1_biases"), slot_stride=conv_end)

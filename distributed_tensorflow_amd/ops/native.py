@@ -441,6 +441,22 @@ def conv5x5_pack(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
     return out
 
 
+def conv5x5_split_pack(w: torch.Tensor, flip: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """HWIO 5x5 filter [5,5,32,64] -> operand of conv5x5_tile(..., split=True): every fp32 value cut into
+    three bf16 values, in MFMA fragment order (csrc/kernels/conv5x5_split.hip). flip=True packs the
+    data-gradient operand. float32-typed storage holding bf16 pairs."""
+    require()
+    if tuple(w.shape) != (5, 5, 32, 64):
+        raise ValueError("conv5x5_split_pack: expected the [5,5,32,64] filter")
+    n = int(hip().conv5x5_split_packed_floats())
+    if out is None:
+        out = torch.empty(n, device=w.device, dtype=torch.float32)
+    elif out.numel() != n:
+        raise ValueError("conv5x5_split_pack: out has the wrong size")
+    hip().conv5x5_split_pack(dict(w=_chk(w, "w"), out=_chk(out, "out"), Cin=32, Cout=64, flip=int(flip)), stream())
+    return out
+
+
 def _pooled_operands(pooled, b: int, who: str) -> dict:
     dp, arg, pm = pooled
     shp = (b, 7, 7, 64)
@@ -450,7 +466,7 @@ def _pooled_operands(pooled, b: int, who: str) -> dict:
 
 
 def conv5x5_tile(x: Optional[torch.Tensor], w: torch.Tensor, *, bias: Optional[torch.Tensor] = None, flip: bool = False,
-                 out: Optional[torch.Tensor] = None, imgs: int = 0, pooled=None, pool_out=None) -> torch.Tensor:
+                 out: Optional[torch.Tensor] = None, imgs: int = 0, pooled=None, pool_out=None, split: bool = False) -> torch.Tensor:
     """5x5 stride-1 SAME convolution over [B,14,14,C] maps with whole images per workgroup.
     flip=False: x has 32 channels, w = conv5x5_pack(filter), returns relu(conv + bias) with 64
     channels. flip=True: x is the 64-channel output gradient, w = the [5,5,32,64] filter itself,
@@ -458,7 +474,9 @@ def conv5x5_tile(x: Optional[torch.Tensor], w: torch.Tensor, *, bias: Optional[t
     pooled=(dp, arg, p) (flip only, x=None) the output gradient is the 2x2 max-pool + ReLU backward
     of dp [B,7,7,64], formed while staging instead of being read from memory. With
     pool_out=(p, arg) (forward form) the kernel writes the 2x2 max pool of the activation
-    ([B,7,7,64] maxima, uint8 winner positions) instead of the activation and returns p."""
+    ([B,7,7,64] maxima, uint8 winner positions) instead of the activation and returns p.
+    split=True: the product runs on the bf16 matrix pipe with operands split three ways and fp32
+    accumulation; w is then conv5x5_split_pack(filter, flip=flip)."""
     require()
     if pooled is not None:
         if not flip or x is not None:
@@ -471,11 +489,11 @@ def conv5x5_tile(x: Optional[torch.Tensor], w: torch.Tensor, *, bias: Optional[t
         b, cin = int(x.shape[0]), int(x.shape[3])
         dev = x.device
     cout = 32 if flip else 64
-    if cin != (64 if flip else 32) or w.numel() != 25 * 32 * 64:
+    if cin != (64 if flip else 32) or w.numel() != (int(hip().conv5x5_split_packed_floats()) if split else 25 * 32 * 64):
         raise ValueError("conv5x5_tile: channel counts must be 32->64 (forward) or 64->32 (flip)")
     if imgs not in (0, 1, 2):
         raise ValueError("conv5x5_tile: imgs must be 0, 1 or 2")
-    d = dict(w=_chk(w, "w"), B=b, Cin=cin, Cout=cout, flip=int(flip), imgs=imgs)
+    d = dict(w=_chk(w, "w"), B=b, Cin=cin, Cout=cout, flip=int(flip), imgs=imgs, split=bool(split))
     if pool_out is not None:
         pm, parg = pool_out
         if flip or tuple(pm.shape) != (b, 7, 7, 64) or tuple(parg.shape) != (b, 7, 7, 64):

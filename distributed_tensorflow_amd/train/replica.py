@@ -218,7 +218,7 @@ class HipReplica(ReplicaBase):
         try:
             with torch.cuda.stream(self.stream):
                 if model == "lenet":
-                    self.step = LeNetHipStep(batch_size, self.arena, optimizer=optimizer, num_buckets=num_buckets)
+                    self.step = LeNetHipStep(batch_size, self.arena, optimizer=optimizer, num_buckets=num_buckets, matmul=matmul)
                 else:
                     # a step whose kernels can return early keeps the atomic gradient flush: behind a
                     # short-circuited kernel the optimizer must find the zeros of the step prologue

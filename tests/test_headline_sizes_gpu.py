@@ -160,12 +160,13 @@ def test_resnet20_step_at_benchmark_batch_matches_autograd(batch, matmul, unfold
     _check_gradients(step.arena, grads_ref, grads32)
 
 
-def test_lenet_step_at_batch_256_matches_autograd(unfold_convolutions):
+@pytest.mark.parametrize("matmul", ["fp32", "bf16x6"])
+def test_lenet_step_at_batch_256_matches_autograd(unfold_convolutions, matmul):
     from distributed_tensorflow_amd.models.lenet import lenet_loss
     from distributed_tensorflow_amd.models.lenet_hip import LeNetHipStep
 
     b = 256
-    step = LeNetHipStep(b, dropout=False)
+    step = LeNetHipStep(b, dropout=False, matmul=matmul)
     g = torch.Generator().manual_seed(3)
     images = torch.rand(b, 28, 28, 1, generator=g) - 0.5
     labels = torch.randint(0, 10, (b,), generator=g)

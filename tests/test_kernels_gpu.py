@@ -249,6 +249,35 @@ def test_conv5x5_tile_data_gradient(b):
     close(got, x.grad)
 
 
+@pytest.mark.parametrize("b", [1, 3, 37, 300, 1030])
+def test_conv5x5_split_forward_data_gradient_and_fusions(b):
+    """Split-operand (bf16x6) form of the whole-image 5x5 kernel: forward with bias + ReLU, forward with the
+    fused max pool, data gradient, data gradient staged from the pooled gradient - each against the exact
+    kernel's reference at the exact kernel's tolerance."""
+    x = rnd(b, 14, 14, 32)
+    wt = rnd(5, 5, 32, 64, scale=0.05)
+    bias = rnd(64, scale=0.3)
+    wf, wb = nv.conv5x5_split_pack(wt), nv.conv5x5_split_pack(wt, flip=True)
+    want = torch.relu(ref.conv2d_same(x, wt, 1) + bias)
+    act = nv.conv5x5_tile(x, wf, bias=bias, split=True)
+    close(act, want)
+    want_p, want_arg = nv.maxpool2x2_fwd(act)
+    p = torch.full((b, 7, 7, 64), -1.0, device=DEV)
+    arg = torch.full((b, 7, 7, 64), 9, device=DEV, dtype=torch.uint8)
+    for _ in range(2):   # the second run must see clean halos again
+        nv.conv5x5_tile(x, wf, bias=bias, pool_out=(p, arg), split=True)
+        assert torch.equal(p, want_p) and torch.equal(arg, want_arg)
+    dy = rnd(b, 14, 14, 64)
+    xg = x.clone().requires_grad_(True)
+    ref.conv2d_same(xg, wt, 1).backward(dy)
+    close(nv.conv5x5_tile(dy, wb, flip=True, split=True), xg.grad)
+    dp = rnd(b, 7, 7, 64)
+    dy2 = nv.maxpool2x2_bwd(dp, arg, p, (b, 14, 14, 64), relu_mask=True)
+    want_dx = nv.conv5x5_tile(dy2, wb, flip=True, split=True)
+    got_dx = nv.conv5x5_tile(None, wb, flip=True, pooled=(dp, arg, p), split=True)
+    close(got_dx, want_dx, tol=1e-6)
+
+
 @pytest.mark.parametrize("case", [c for c in CONV_CASES if c[3] >= 16])
 def test_conv_dgrad(case):
     b, h, w, cin, cout, ks, s = case

@@ -21,12 +21,13 @@ def _rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
 
-def test_lenet_step_matches_autograd():
+@pytest.mark.parametrize("matmul", ["fp32", "bf16x6"])
+def test_lenet_step_matches_autograd(matmul):
     from distributed_tensorflow_amd.models.lenet import lenet_loss
     from distributed_tensorflow_amd.models.lenet_hip import LeNetHipStep
 
     b = 12
-    step = LeNetHipStep(b, dropout=False, num_buckets=2)
+    step = LeNetHipStep(b, dropout=False, num_buckets=2, matmul=matmul)
     g = torch.Generator().manual_seed(3)
     images = torch.rand(b, 28, 28, 1, generator=g) - 0.5
     labels = torch.randint(0, 10, (b,), generator=g)
