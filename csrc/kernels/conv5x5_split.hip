@@ -50,11 +50,16 @@ struct S5 {
   static constexpr int CW = COUT / CSPLIT;           // output channels of one workgroup (blockIdx.y picks the slice)
   static constexpr int KS = CIN / 32;                // K = 32 steps per tap
   static constexpr int PSB = CIN == 32 ? 96 : 144;   // bytes per pixel and plane: an odd number of 16-byte slots (+2, +1 of padding)
-  static constexpr int PLANE = kPW * kPW * PSB;      // bytes per plane
+  // (16 pixels across rows of 14 make about every second 16-lane group of a ds_read_b128 two-way
+  // conflicted; 128 bytes of row padding remove that at 32 channels and change no measured time)
+  static constexpr int ROWB = kPW * PSB;             // bytes per plane row
+  static constexpr int PLANE = kPW * ROWB;           // bytes per plane
   static constexpr int NT = (kImgPx + 15) / 16;      // 13 pixel tiles (the last one a quarter full)
   static constexpr int MT = CW / 16;                 // output-channel tiles of the workgroup
   static constexpr int MT_ALL = COUT / 16;
-  static constexpr int WPM = 4 / MT;                 // waves sharing one output-channel tile
+  static constexpr int MW = MT >= 2 ? 2 : 1;         // output-channel tiles per wave: each pixel operand read feeds MW tiles
+  static constexpr int MG = MT / MW;                 // wave groups along the output channels
+  static constexpr int WPM = 4 / MG;                 // waves sharing one group of output-channel tiles
   static constexpr int NTW = (NT + WPM - 1) / WPM;   // pixel tiles per wave
   static constexpr int C4 = CIN / 4;
   static constexpr int CHUNKS = kImgPx * C4;
@@ -71,7 +76,7 @@ template <int CIN, int COUT, bool BIAS_RELU, bool POOLED, bool POOLOUT, int CSPL
 __global__ __launch_bounds__(256) void conv5x5_split_kernel(Conv5x5Args a) {
   DTF_ABORT_GUARD(a);
   using G = S5<CIN, COUT, CSPLIT>;
-  constexpr int KS = G::KS, PSB = G::PSB, PLANE = G::PLANE, NTW = G::NTW;
+  constexpr int KS = G::KS, PSB = G::PSB, ROWB = G::ROWB, PLANE = G::PLANE, NTW = G::NTW;
   const int cbase = CSPLIT > 1 ? (int)blockIdx.y * G::CW : 0;   // first output channel of this workgroup
   static_assert(!POOLED || CIN == 64, "pooled staging is the data-gradient form");
   static_assert(!POOLOUT || (BIAS_RELU && COUT == 64), "the fused max pool follows the forward form");
@@ -79,7 +84,8 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(Conv5x5Args a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, n = lane & 15;
-  const int mtile = wave % G::MT, nsub = wave / G::MT;
+  constexpr int MW = G::MW;
+  const int mtile = (wave % G::MG) * MW, nsub = wave / G::MG;   // first of the wave's MW output-channel tiles
   const int co0 = mtile * 16;
 
   // zero the planes once: the halo is never written again
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(Conv5x5Args a) {
   for (int i = 0; i < NTW; ++i) {
     int p = (nsub * NTW + i) * 16 + n;
     if (p > kImgPx - 1) p = kImgPx - 1;   // a tile beyond the image multiplies a copy of the last pixel (not stored)
-    boff[i] = ((p / kHW) * kPW + p % kHW) * PSB + 16 * q;
+    boff[i] = (p / kHW) * ROWB + (p % kHW) * PSB + 16 * q;
   }
   // staging: chunk c (4 channels of a pixel) of the image is contiguous in global memory; its LDS home is fixed
   int sdst[G::NPF];
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(Conv5x5Args a) {
   for (int k = 0; k < G::NPF; ++k) {
     const int c = tid + 256 * k;
     const int px = (c < G::CHUNKS ? c : 0) / G::C4, c4 = c % G::C4;
-    sdst[k] = ((px / kHW + 2) * kPW + px % kHW + 2) * PSB + 8 * c4;
+    sdst[k] = (px / kHW + 2) * ROWB + (px % kHW + 2) * PSB + 8 * c4;
   }
   floatx4 pf[POOLED ? 1 : G::NPF];
   PooledChunk pc[POOLED ? kNpc : 1];
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(Conv5x5Args a) {
     for (int k = 0; k < kNpc; ++k) {
       const int cc = min(tid + 256 * k, kCellChunks - 1);
       const int cell = cc >> 4;
-      pdst[k] = ((2 * (cell / 7) + 2) * kPW + 2 * (cell % 7) + 2) * PSB + 8 * (cc & 15);
+      pdst[k] = (2 * (cell / 7) + 2) * ROWB + (2 * (cell % 7) + 2) * PSB + 8 * (cc & 15);
     }
   }
   auto fetch = [&](int img) {
@@ -135,10 +141,12 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(Conv5x5Args a) {
     *reinterpret_cast<uintx2*>(lds_b + off + 2 * PLANE) = l;
   };
 
-  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  float bias4[MW][4] = {};
   if constexpr (BIAS_RELU) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bias4[i] = a.bias[cbase + co0 + 4 * q + i];
+    for (int j = 0; j < MW; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bias4[j][i] = a.bias[cbase + co0 + 16 * j + 4 * q + i];
   }
   // this lane's filter fragments: [tap][channel tile][K step][part][lane] x 16 bytes
   const uintx4* wlane = reinterpret_cast<const uintx4*>(a.w) + (size_t)((cbase / 16 + mtile) * KS) * 3 * 64 + lane;
@@ -154,8 +162,8 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(Conv5x5Args a) {
         if (tid + 256 * k < kCellChunks) {
           put(pdst[k], pooled_value(pc[k], 0));
           put(pdst[k] + PSB, pooled_value(pc[k], 1));
-          put(pdst[k] + kPW * PSB, pooled_value(pc[k], 2));
-          put(pdst[k] + (kPW + 1) * PSB, pooled_value(pc[k], 3));
+          put(pdst[k] + ROWB, pooled_value(pc[k], 2));
+          put(pdst[k] + ROWB + PSB, pooled_value(pc[k], 3));
         }
     } else {
 #pragma unroll
@@ -165,74 +173,78 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(Conv5x5Args a) {
     __syncthreads();
     if (img + (int)gridDim.x < a.B) fetch(img + gridDim.x);
 
-    floatx4 acc[NTW];
+    floatx4 acc[MW][NTW];
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MW; ++j)
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) acc[j][i] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    uintx4 wcur[KS][3], wnxt[KS][3];
+    uintx4 wcur[MW * KS][3], wnxt[MW * KS][3];   // [tile j][K step] flattened: consecutive in the packed filter
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+    for (int ks = 0; ks < MW * KS; ++ks)
 #pragma unroll
       for (int part = 0; part < 3; ++part) wcur[ks][part] = wlane[(ks * 3 + part) * 64];
+    // A tap is U units of (K step, group of up to four pixel tiles); the pixel-operand reads of the next unit -
+    // the first unit of the next tap after a tap's last - are in flight while this unit's MFMAs run.
+    constexpr int kGroup = (KS * ((NTW + 3) / 4)) % 2 == 0 ? 4 : 2;
+    constexpr int NG = (NTW + kGroup - 1) / kGroup;
+    constexpr int U = KS * NG;
+    static_assert(U % 2 == 0, "two operand buffers alternate with a fixed phase per tap");
+    bf16x8 bh[2][kGroup], bm[2][kGroup], bl[2][kGroup];
+    auto read_unit = [&](int u, int toff_, int buf) {
+      const int ks = u / NG, i0 = (u % NG) * kGroup;
+#pragma unroll
+      for (int v = 0; v < kGroup; ++v)
+        if (i0 + v < NTW) {
+          const unsigned char* p = lds_b + toff_ + boff[i0 + v] + 64 * ks;
+          bh[buf][v] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uintx4*>(p));
+          bm[buf][v] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uintx4*>(p + PLANE));
+          bl[buf][v] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uintx4*>(p + 2 * PLANE));
+        }
+    };
     int toff = 0;   // byte offset of the tap inside the window
+    read_unit(0, 0, 0);
 #pragma unroll 1
-    for (int kh = 0; kh < 5; ++kh) {
-#pragma unroll 1
-      for (int kw = 0; kw < 5; ++kw) {
-        const int tap = kh * 5 + kw;
-        if (tap < 24) {
-          const uintx4* wn = wlane + (size_t)(tap + 1) * W_TAP;
+    for (int tap = 0; tap < 25; ++tap) {
+      {
+        // no branch around the prefetch (the last tap loads its own fragments again): with one, the compiler
+        // has to assume the path without newer loads in flight and waits for these right away
+        const uintx4* wn = wlane + (size_t)min(tap + 1, 24) * W_TAP;
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks)
+        for (int ks = 0; ks < MW * KS; ++ks)
 #pragma unroll
-            for (int part = 0; part < 3; ++part) wnxt[ks][part] = wn[(ks * 3 + part) * 64];
-        }
-        const unsigned char* base = lds_b + toff;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8 wh = __builtin_bit_cast(bf16x8, wcur[ks][0]), wm = __builtin_bit_cast(bf16x8, wcur[ks][1]);
-          const bf16x8 wl = __builtin_bit_cast(bf16x8, wcur[ks][2]);
-          // four pixel tiles at a time, so that consecutive MFMAs write different accumulators
-#pragma unroll
-          for (int i0 = 0; i0 < NTW; i0 += 4) {
-            constexpr int kGroup = 4;
-            bf16x8 bh[kGroup], bm[kGroup], bl[kGroup];
-#pragma unroll
-            for (int u = 0; u < kGroup; ++u)
-              if (i0 + u < NTW) {
-                const unsigned char* p = base + boff[i0 + u] + 64 * ks;
-                bh[u] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uintx4*>(p));
-                bm[u] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uintx4*>(p + PLANE));
-                bl[u] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uintx4*>(p + 2 * PLANE));
-              }
-            // small terms first, then the large ones
-#pragma unroll
-            for (int u = 0; u < kGroup; ++u)
-              if (i0 + u < NTW) acc[i0 + u] = DTF_MFMA_BF16(wl, bh[u], acc[i0 + u]);
-#pragma unroll
-            for (int u = 0; u < kGroup; ++u)
-              if (i0 + u < NTW) acc[i0 + u] = DTF_MFMA_BF16(wh, bl[u], acc[i0 + u]);
-#pragma unroll
-            for (int u = 0; u < kGroup; ++u)
-              if (i0 + u < NTW) acc[i0 + u] = DTF_MFMA_BF16(wm, bm[u], acc[i0 + u]);
-#pragma unroll
-            for (int u = 0; u < kGroup; ++u)
-              if (i0 + u < NTW) acc[i0 + u] = DTF_MFMA_BF16(wm, bh[u], acc[i0 + u]);
-#pragma unroll
-            for (int u = 0; u < kGroup; ++u)
-              if (i0 + u < NTW) acc[i0 + u] = DTF_MFMA_BF16(wh, bm[u], acc[i0 + u]);
-#pragma unroll
-            for (int u = 0; u < kGroup; ++u)
-              if (i0 + u < NTW) acc[i0 + u] = DTF_MFMA_BF16(wh, bh[u], acc[i0 + u]);
-          }
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-          for (int part = 0; part < 3; ++part) wcur[ks][part] = wnxt[ks][part];
-        toff += PSB;
+          for (int part = 0; part < 3; ++part) wnxt[ks][part] = wn[(ks * 3 + part) * 64];
       }
-      toff += (kPW - 5) * PSB;
+      const int toff_next = tap == 24 ? toff : toff + ((tap % 5) == 4 ? ROWB - 4 * PSB : PSB);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ks = u / NG, i0 = (u % NG) * kGroup, b = u & 1;
+        if (u + 1 < U) read_unit(u + 1, toff, b ^ 1);
+        else read_unit(0, toff_next, b ^ 1);   // unconditional for the same reason (the last tap reads its own again)
+        __builtin_amdgcn_sched_barrier(0);
+        // small terms first, then the large ones; the wave's tiles alternate
+        auto term = [&](int wpart, const bf16x8 (&bp)[2][kGroup]) __attribute__((always_inline)) {
+#pragma unroll
+          for (int j = 0; j < MW; ++j) {
+            const bf16x8 wv = __builtin_bit_cast(bf16x8, wcur[j * KS + ks][wpart]);
+#pragma unroll
+            for (int v = 0; v < kGroup; ++v)
+              if (i0 + v < NTW) acc[j][i0 + v] = DTF_MFMA_BF16(wv, bp[b][v], acc[j][i0 + v]);
+          }
+        };
+        term(2, bh);
+        term(0, bl);
+        term(1, bm);
+        term(1, bh);
+        term(0, bm);
+        term(0, bh);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < MW * KS; ++ks)
+#pragma unroll
+        for (int part = 0; part < 3; ++part) wcur[ks][part] = wnxt[ks][part];
+      toff = toff_next;
     }
 
     // lane holds output channels co0 + 4 q .. + 3 of pixel 16 t + n
@@ -243,13 +255,16 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(Conv5x5Args a) {
     for (int i = 0; i < NTW; ++i) {
       const int p = (nsub * NTW + i) * 16 + n;
       if (p < kImgPx) {
-        floatx4 o = acc[i];
-        if constexpr (BIAS_RELU) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r] + bias4[r], 0.f);
+        for (int j = 0; j < MW; ++j) {
+          floatx4 o = acc[j][i];
+          if constexpr (BIAS_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r] + bias4[j][r], 0.f);
+          }
+          if constexpr (POOLOUT) *reinterpret_cast<floatx4*>(lds_f + p * G::OS + co0 + 16 * j + 4 * q) = o;
+          else *reinterpret_cast<floatx4*>(yt + (size_t)p * COUT + 16 * j) = o;
         }
-        if constexpr (POOLOUT) *reinterpret_cast<floatx4*>(lds_f + p * G::OS + co0 + 4 * q) = o;
-        else *reinterpret_cast<floatx4*>(yt + (size_t)p * COUT) = o;
       }
     }
     if constexpr (POOLOUT) {
