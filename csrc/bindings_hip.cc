@@ -183,7 +183,9 @@ PYBIND11_MODULE(_hip, m) {
     Conv5x5WgradArgs a{};
     P(x, const float); P(dy, const float); P(dw, float); V(slot_stride); V(B); P(partials, float);
     P(pool_dp, const float); P(pool_arg, const unsigned char); P(pool_p, const float);
-    conv5x5_wgrad(a, as_stream(stream));
+    const bool split = d.contains("split") && d["split"].cast<bool>();
+    if (split) conv5x5_wgrad_split(a, as_stream(stream));
+    else conv5x5_wgrad(a, as_stream(stream));
   });
   m.def("conv5x5_wgrad_parts", &conv5x5_wgrad_parts);
   m.def("partial_sum", [](const py::dict& d, uint64_t stream) {

@@ -272,6 +272,8 @@ struct Conv5x5WgradArgs {
 };
 int conv5x5_wgrad_parts(int B);
 void conv5x5_wgrad(const Conv5x5WgradArgs& a, hipStream_t stream);
+// Opt-in split-operand ("bf16x6") form of conv5x5_wgrad (conv5x5_split.hip): same arguments and results layout.
+void conv5x5_wgrad_split(const Conv5x5WgradArgs& a, hipStream_t stream);
 bool conv5x5_tile_supported(int H, int W, int Cin, int Cout);
 void conv5x5_tile(const Conv5x5Args& a, hipStream_t stream);
 void conv5x5_pack(const Conv5x5PackArgs& a, hipStream_t stream);

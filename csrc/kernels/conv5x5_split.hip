@@ -298,6 +298,237 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(Conv5x5Args a) {
   }
 }
 
+// ---- filter gradient of the same layer on the bf16 pipe: dw[tap][ci][co] += sum over pixels x[p + tap][ci] * dy[p][co]
+//
+// As in the exact kernel (conv5x5_tile.hip: conv5x5_wgrad_kernel) one image per workgroup tile sits in LDS, the
+// 25 x 32 x 64 outputs live in the accumulators of the four waves for the whole kernel (wave = one 16-channel
+// slice of ci x two of co, all taps: 50 tiles, 200 registers) and the pixel loop has no barrier. Here K = 32
+// pixels per MFMA: 7 steps cover the 196 pixels (the 28 pixels past the end are zero in dy). Both operands have
+// the pixels along K, so both come out of pixel-major bf16 planes through transposed reads
+// (ds_read_b64_tr_b16: lane group q holds pixels 4 q .. 4 q + 3 and 16 + 4 q .. of the step, for x and dy alike):
+//   x:  [part h, m, l][16-channel half][18 x 18 padded pixels][32 bytes]  - a tap is an immediate offset
+//   dy: [part][16-channel tile of co][224 pixels][32 bytes]
+// Per step and wave 150 + 12 transposed reads feed 300 MFMAs; the reads of tap t + 1 (after the last tap: of
+// the next step's first) are in flight under the MFMAs of tap t.
+constexpr int kWsXHalf = kPW * kPW * 32;          // bytes of one 16-channel half plane of x
+constexpr int kWsXPart = 2 * kWsXHalf;
+constexpr int kWsKSteps = (kImgPx + 31) / 32;     // 7
+constexpr int kWsYPx = kWsKSteps * 32;            // 224
+constexpr int kWsYTile = kWsYPx * 32;             // bytes of one 16-channel tile plane of dy
+constexpr int kWsYPart = 4 * kWsYTile;
+constexpr int kWsLds = 3 * kWsXPart + 3 * kWsYPart;
+static_assert(kWsLds <= (int)kLdsBudget, "x and dy planes of one image");
+constexpr int kWsXChunks = kImgPx * 8, kWsYChunks = kImgPx * 16;
+constexpr int kWsNpfX = (kWsXChunks + 255) / 256, kWsNpfY = (kWsYChunks + 255) / 256;
+
+// TSPLIT = 2: two workgroups per image, each with its own copy of the staged image and half of the 25 taps
+// (13 and 12) - for batches with fewer images than CUs.
+template <bool POOLED, int TSPLIT>
+__global__ __launch_bounds__(256) void conv5x5_wgrad_split_kernel(Conv5x5WgradArgs a) {
+  DTF_ABORT_GUARD(a);
+  constexpr int NTAP = (25 + TSPLIT - 1) / TSPLIT;
+  static_assert(NTAP % 2 == 1, "the last tap of a step uses the first operand buffer again");
+  const int tap0 = TSPLIT > 1 ? (int)blockIdx.y * NTAP : 0;
+  int tap_off[TSPLIT > 1 ? NTAP : 1];   // TSPLIT = 1: immediates
+  if constexpr (TSPLIT > 1) {
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+      const int tap = min(tap0 + t, 24);   // a slot past the last tap reads tap 24 and is not used
+      tap_off[t] = ((tap / 5) * kPW + tap % 5) * 32;
+    }
+  }
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_b[];
+  unsigned char* sx = lds_b;
+  unsigned char* sy = lds_b + 3 * kWsXPart;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, n = lane & 15;
+  const int v = wave >> 1, h = wave & 1;   // ci slice 16 v .., co slices 32 h .. and 32 h + 16 ..
+  const int tr_j = (lane >> 2) & 3, tr_c = lane & 3;   // transposed read: this lane points at pixel 4 q + tr_j, channels 4 tr_c ..
+
+  // zero once: the halo of x and the pixels of dy past the image are never written
+  for (int i = tid; i < kWsLds / 16; i += 256) reinterpret_cast<uintx4*>(lds_b)[i] = uintx4{0u, 0u, 0u, 0u};
+
+  int xdst[kWsNpfX], ydst[POOLED ? 1 : kWsNpfY];
+#pragma unroll
+  for (int k = 0; k < kWsNpfX; ++k) {
+    const int c = tid + 256 * k;
+    const int px = (c < kWsXChunks ? c : 0) >> 3, c4 = c & 7;
+    xdst[k] = (c4 >> 2) * kWsXHalf + ((px / kHW + 2) * kPW + px % kHW + 2) * 32 + 8 * (c4 & 3);
+  }
+  if constexpr (!POOLED) {
+#pragma unroll
+    for (int k = 0; k < kWsNpfY; ++k) {
+      const int c = tid + 256 * k;
+      ydst[k] = ((c & 15) >> 2) * kWsYTile + ((c < kWsYChunks ? c : 0) >> 4) * 32 + 8 * (c & 3);
+    }
+  }
+  floatx4 pfx[kWsNpfX], pfy[POOLED ? 1 : kWsNpfY];
+  PooledChunk pc[POOLED ? kNpc : 1];
+  int pdst[POOLED ? kNpc : 1];
+  if constexpr (POOLED) {
+#pragma unroll
+    for (int k = 0; k < kNpc; ++k) {
+      const int cc = min(tid + 256 * k, kCellChunks - 1);
+      const int cell = cc >> 4;
+      pdst[k] = ((cc & 15) >> 2) * kWsYTile + (2 * (cell / 7) * kHW + 2 * (cell % 7)) * 32 + 8 * (cc & 3);
+    }
+  }
+  auto fetch = [&](int img) {
+    const floatx4* xs = reinterpret_cast<const floatx4*>(a.x + (size_t)img * kImgPx * 32);
+#pragma unroll
+    for (int k = 0; k < kWsNpfX; ++k)
+      if (tid + 256 * k < kWsXChunks) pfx[k] = xs[tid + 256 * k];
+    if constexpr (POOLED) {
+#pragma unroll
+      for (int k = 0; k < kNpc; ++k)
+        if (tid + 256 * k < kCellChunks) pooled_fetch(a.pool_dp, a.pool_arg, a.pool_p, img, tid + 256 * k, pc[k]);
+    } else {
+      const floatx4* ys = reinterpret_cast<const floatx4*>(a.dy + (size_t)img * kImgPx * 64);
+#pragma unroll
+      for (int k = 0; k < kWsNpfY; ++k)
+        if (tid + 256 * k < kWsYChunks) pfy[k] = ys[tid + 256 * k];
+    }
+  };
+  auto put = [&](unsigned char* base, int part_stride, int off, const floatx4& val) {
+    uintx2 ph, pm, pl;
+    split3(val, ph, pm, pl);
+    *reinterpret_cast<uintx2*>(base + off) = ph;
+    *reinterpret_cast<uintx2*>(base + off + part_stride) = pm;
+    *reinterpret_cast<uintx2*>(base + off + 2 * part_stride) = pl;
+  };
+
+  floatx4 acc[NTAP][2];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) acc[t][0] = acc[t][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  // lane addresses of K step s: pixels 32 s + 4 q + tr_j and 16 more (x: clamped to the image; what a pixel past
+  // the end multiplies is zero in dy)
+  auto x_addr = [&](int p) {
+    p = min(p, kImgPx - 1);
+    return v * kWsXHalf + ((p / kHW) * kPW + p % kHW) * 32 + 8 * tr_c;
+  };
+  const int y_lane = 2 * h * kWsYTile + (4 * q + tr_j) * 32 + 8 * tr_c;
+
+  int img = blockIdx.x;
+  if (img < a.B) fetch(img);
+  for (; img < a.B; img += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kWsNpfX; ++k)
+      if (tid + 256 * k < kWsXChunks) put(sx, kWsXPart, xdst[k], pfx[k]);
+    if constexpr (POOLED) {
+#pragma unroll
+      for (int k = 0; k < kNpc; ++k)
+        if (tid + 256 * k < kCellChunks) {
+          put(sy, kWsYPart, pdst[k], pooled_value(pc[k], 0));
+          put(sy, kWsYPart, pdst[k] + 32, pooled_value(pc[k], 1));
+          put(sy, kWsYPart, pdst[k] + kHW * 32, pooled_value(pc[k], 2));
+          put(sy, kWsYPart, pdst[k] + (kHW + 1) * 32, pooled_value(pc[k], 3));
+        }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kWsNpfY; ++k)
+        if (tid + 256 * k < kWsYChunks) put(sy, kWsYPart, ydst[k], pfy[k]);
+    }
+    __syncthreads();
+    if (img + (int)gridDim.x < a.B) fetch(img + gridDim.x);
+
+    uintx2 abuf[2][3][2], anext[3][2];          // [buffer][part][K half]
+    uintx2 bcur[2][3][2], bnext[2][3][2];       // [co tile][part][K half]
+    auto read_a = [&](int xa0, int xa1, int t, uintx2 (&dst)[3][2]) __attribute__((always_inline)) {
+      int off;
+      if constexpr (TSPLIT > 1) off = tap_off[t];
+      else off = ((t / 5) * kPW + t % 5) * 32;
+#pragma unroll
+      for (int part = 0; part < 3; ++part) {
+        dst[part][0] = lds_read_tr(sx + xa0 + off + part * kWsXPart);
+        dst[part][1] = lds_read_tr(sx + xa1 + off + part * kWsXPart);
+      }
+    };
+    auto read_b = [&](int s, uintx2 (&dst)[2][3][2]) __attribute__((always_inline)) {
+      const unsigned char* p = sy + y_lane + s * (32 * 32);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+          dst[j][part][0] = lds_read_tr(p + j * kWsYTile + part * kWsYPart);
+          dst[j][part][1] = lds_read_tr(p + j * kWsYTile + part * kWsYPart + 16 * 32);
+        }
+    };
+    int xa0 = x_addr(4 * q + tr_j), xa1 = x_addr(16 + 4 * q + tr_j);
+    read_b(0, bcur);
+    read_a(xa0, xa1, 0, abuf[0]);
+#pragma unroll 1
+    for (int s = 0; s < kWsKSteps; ++s) {
+      const int sn = min(s + 1, kWsKSteps - 1);   // the last step reads its own operands again: no branch around a prefetch
+      const int xn0 = x_addr(32 * sn + 4 * q + tr_j), xn1 = x_addr(32 * sn + 16 + 4 * q + tr_j);
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) {
+        if (t + 1 < NTAP) read_a(xa0, xa1, t + 1, abuf[(t + 1) & 1]);
+        else read_a(xn0, xn1, 0, anext);
+        if (t == NTAP / 2) read_b(sn, bnext);
+        __builtin_amdgcn_sched_barrier(0);
+        const uintx2 (&ab)[3][2] = abuf[t & 1];
+        const bf16x8 ah = frag8(ab[0][0], ab[0][1]), am = frag8(ab[1][0], ab[1][1]), al = frag8(ab[2][0], ab[2][1]);
+        // small terms first; the two co tiles alternate
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[t][j] = DTF_MFMA_BF16(al, frag8(bcur[j][0][0], bcur[j][0][1]), acc[t][j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[t][j] = DTF_MFMA_BF16(ah, frag8(bcur[j][2][0], bcur[j][2][1]), acc[t][j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[t][j] = DTF_MFMA_BF16(am, frag8(bcur[j][1][0], bcur[j][1][1]), acc[t][j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[t][j] = DTF_MFMA_BF16(am, frag8(bcur[j][0][0], bcur[j][0][1]), acc[t][j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[t][j] = DTF_MFMA_BF16(ah, frag8(bcur[j][1][0], bcur[j][1][1]), acc[t][j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[t][j] = DTF_MFMA_BF16(ah, frag8(bcur[j][0][0], bcur[j][0][1]), acc[t][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int part = 0; part < 3; ++part)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          abuf[0][part][kh] = anext[part][kh];
+          bcur[0][part][kh] = bnext[0][part][kh];
+          bcur[1][part][kh] = bnext[1][part][kh];
+        }
+      xa0 = xn0;
+      xa1 = xn1;
+    }
+  }
+
+  // lane holds dw[tap][ci = 16 v + 4 q + i][co = 32 h + 16 j + n]
+  const int lane_off = (16 * v + 4 * q) * 64 + 32 * h + n;
+  if (a.partials) {
+    float* dst = a.partials + (size_t)blockIdx.x * (25 * 2048) + (size_t)tap0 * 2048 + lane_off;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+      if (tap0 + t < 25) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dst[t * 2048 + i * 64 + 16 * j] = acc[t][j][i];
+      }
+    }
+    return;
+  }
+  float* dst = a.dw + (a.slot_stride ? (size_t)(blockIdx.x & (kStatSlots - 1)) * a.slot_stride : 0) + (size_t)tap0 * 2048 + lane_off;
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    if (tap0 + t < 25) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float sum = acc[t][j][i];
+          if (sum != 0.f) atomicAdd(dst + t * 2048 + i * 64 + 16 * j, sum);
+        }
+    }
+  }
+}
+
 // HWIO filter [25][Cin][Cout] -> MFMA A fragments, bf16 element i of [tap][row tile][K step][part][lane][8]:
 // forward: rows = output channels, K = input channels; flip (data gradient): tap t takes filter tap
 // 24 - t, rows = input channels, K = output channels.
@@ -367,6 +598,32 @@ void conv5x5_split(const Conv5x5Args& a, hipStream_t stream) {
     return launch_s5<64, 32, false>(a, stream);
   }
   throw std::runtime_error("conv5x5_split: unsupported channel counts / direction");
+}
+
+// Same interface as conv5x5_wgrad (conv5x5_wgrad_parts(B) partial results, per-XCD copies, pooled staging).
+void conv5x5_wgrad_split(const Conv5x5WgradArgs& a, hipStream_t stream) {
+  if (a.B < 1) throw std::runtime_error("conv5x5_wgrad_split: empty batch");
+  const size_t shmem = (size_t)kWsLds;
+  static const bool once = [&] {
+    ensure_dynamic_lds(reinterpret_cast<const void*>(conv5x5_wgrad_split_kernel<false, 1>), shmem);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(conv5x5_wgrad_split_kernel<true, 1>), shmem);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(conv5x5_wgrad_split_kernel<false, 2>), shmem);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(conv5x5_wgrad_split_kernel<true, 2>), shmem);
+    return true;
+  }();
+  (void)once;
+  const int grid = conv5x5_wgrad_parts(a.B);
+  const bool halves = a.B < 256;   // fewer images than CUs: two workgroups per image, 13 and 12 of the 25 taps each
+  const dim3 g(grid, halves ? 2 : 1);
+  if (a.pool_dp) {
+    if (!a.pool_arg || !a.pool_p) throw std::runtime_error("conv5x5_wgrad_split: pooled staging needs dp, arg and p");
+    if (halves) launch("conv5x5_wgrad_split", conv5x5_wgrad_split_kernel<true, 2>, g, dim3(256), shmem, stream, a);
+    else launch("conv5x5_wgrad_split", conv5x5_wgrad_split_kernel<true, 1>, g, dim3(256), shmem, stream, a);
+  } else {
+    if (!a.dy) throw std::runtime_error("conv5x5_wgrad_split: null output gradient");
+    if (halves) launch("conv5x5_wgrad_split", conv5x5_wgrad_split_kernel<false, 2>, g, dim3(256), shmem, stream, a);
+    else launch("conv5x5_wgrad_split", conv5x5_wgrad_split_kernel<false, 1>, g, dim3(256), shmem, stream, a);
+  }
 }
 
 }  // namespace dtf

@@ -132,7 +132,7 @@ class LeNetHipStep(StepProgramBase):
                 # conv2 filter gradient: per-workgroup partial results, one reduction into the arena
                 if not hasattr(self, "_w2_parts"):
                     self._w2_parts = torch.empty(nv.conv5x5_wgrad_parts(B), 25 * 32 * 64, device=self.device, dtype=torch.float32)
-                nv.conv5x5_wgrad(self.p1, None, a.grad("conv2_weights"), partials=self._w2_parts, pooled=pooled2)
+                nv.conv5x5_wgrad(self.p1, None, a.grad("conv2_weights"), partials=self._w2_parts, pooled=pooled2, split=split)
                 # data gradient: the same kernel over the unpacked filter, taps walked backwards
                 if split:
                     nv.conv5x5_tile(None, self.wpk2_t, flip=True, out=self.dp1, pooled=pooled2, split=True)

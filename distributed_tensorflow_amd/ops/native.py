@@ -525,18 +525,19 @@ def conv5x5_wgrad_parts(batch: int) -> int:
 
 
 def conv5x5_wgrad(x: torch.Tensor, dy: Optional[torch.Tensor], dw: torch.Tensor, slot_stride: int = 0,
-                  partials: Optional[torch.Tensor] = None, pooled=None) -> None:
+                  partials: Optional[torch.Tensor] = None, pooled=None, split: bool = False) -> None:
     """dw [5,5,32,64] += filter gradient of the 5x5 SAME convolution over [B,14,14,32] inputs with
     output gradient dy [B,14,14,64]; with slot_stride into the per-XCD copies starting at dw.
     partials [conv5x5_wgrad_parts(B), 51200]: the workgroups store their partial results there
     without atomics and one partial_sum adds them to dw. pooled=(dp, arg, p) with dy=None: the
-    output gradient is the max-pool + ReLU backward of dp [B,7,7,64], formed while staging."""
+    output gradient is the max-pool + ReLU backward of dp [B,7,7,64], formed while staging.
+    split=True: on the bf16 matrix pipe with both operands split three ways, fp32 accumulation."""
     require()
     b = int(x.shape[0])
     n = 25 * 32 * 64
     if tuple(x.shape) != (b, 14, 14, 32) or dw.numel() != n:
         raise ValueError("conv5x5_wgrad: expected x [B,14,14,32], dw [5,5,32,64]")
-    d = dict(x=_chk(x, "x"), dw=_chk(dw, "dw"), slot_stride=slot_stride, B=b)
+    d = dict(x=_chk(x, "x"), dw=_chk(dw, "dw"), slot_stride=slot_stride, B=b, split=bool(split))
     if pooled is not None:
         if dy is not None:
             raise ValueError("conv5x5_wgrad: pass either dy or pooled")

@@ -181,22 +181,24 @@ def test_conv5x5_tile_forward(b, imgs):
     close(got, want)
 
 
-@pytest.mark.parametrize("b", [1, 5, 300])
-def test_conv5x5_filter_gradient(b):
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("b", [1, 5, 300, 1030])
+def test_conv5x5_filter_gradient(b, split):
+    """split=True: the bf16x6 form on the bf16 matrix pipe, held to the exact kernel's tolerance."""
     x = rnd(b, 14, 14, 32)
     dy = rnd(b, 14, 14, 64)
     wt = rnd(5, 5, 32, 64, scale=0.05).requires_grad_(True)
     ref.conv2d_same(x, wt, 1).backward(dy)
     slots = torch.zeros(nv.STAT_SLOTS, 25 * 32 * 64 + 256, device=DEV)
-    nv.conv5x5_wgrad(x, dy, slots[0, :25 * 32 * 64].view(5, 5, 32, 64), slot_stride=slots.shape[1])
+    nv.conv5x5_wgrad(x, dy, slots[0, :25 * 32 * 64].view(5, 5, 32, 64), slot_stride=slots.shape[1], split=split)
     close(slots.sum(0)[:25 * 32 * 64].view(5, 5, 32, 64), wt.grad, tol=5e-4)
     dw = torch.zeros(5, 5, 32, 64, device=DEV)
-    nv.conv5x5_wgrad(x, dy, dw)
+    nv.conv5x5_wgrad(x, dy, dw, split=split)
     close(dw, wt.grad, tol=5e-4)
     # per-workgroup partial results (no atomics) summed by one reduction; the buffer starts dirty
     ws = torch.full((nv.conv5x5_wgrad_parts(b), 25 * 32 * 64), 7.0, device=DEV)
     dw2 = torch.ones(5, 5, 32, 64, device=DEV)
-    nv.conv5x5_wgrad(x, dy, dw2, partials=ws)
+    nv.conv5x5_wgrad(x, dy, dw2, partials=ws, split=split)
     close(dw2 - 1.0, wt.grad, tol=5e-4)
 
 
@@ -217,8 +219,9 @@ def test_conv5x5_forward_with_fused_pool(b, imgs):
     assert torch.equal(p, want_p)
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("b", [1, 6, 270])
-def test_conv5x5_backward_from_the_pooled_gradient(b):
+def test_conv5x5_backward_from_the_pooled_gradient(b, split):
     """Data and filter gradient of the second LeNet convolution computed straight from the
     gradient at the max pool (pool + ReLU backward formed while staging) equal the unfused chain."""
     x = rnd(b, 14, 14, 32)
@@ -232,10 +235,10 @@ def test_conv5x5_backward_from_the_pooled_gradient(b):
     got_dx = nv.conv5x5_tile(None, wt, flip=True, pooled=(dp, arg, pooled))
     close(got_dx, want_dx, tol=1e-6)
     want_dw = torch.zeros(5, 5, 32, 64, device=DEV)
-    nv.conv5x5_wgrad(x, dy, want_dw)
+    nv.conv5x5_wgrad(x, dy, want_dw, split=split)
     ws = torch.empty(nv.conv5x5_wgrad_parts(b), 25 * 32 * 64, device=DEV)
     got_dw = torch.zeros(5, 5, 32, 64, device=DEV)
-    nv.conv5x5_wgrad(x, None, got_dw, partials=ws, pooled=(dp, arg, pooled))
+    nv.conv5x5_wgrad(x, None, got_dw, partials=ws, pooled=(dp, arg, pooled), split=split)
     close(got_dw, want_dw, tol=1e-5)
 
 
