@@ -447,7 +447,7 @@ def main() -> None:
         if matmul == "fp32":
             return "fp32 (v_mfma_f32_16x16x4_f32)"
         if lenet:
-            return "bf16x6 split, fp32 accumulate (second convolution: forward and data gradient; everything else fp32 MFMA)"
+            return "bf16x6 split, fp32 accumulate (second convolution: forward, data gradient and filter gradient; everything else fp32 MFMA)"
         return ("bf16x6 split, fp32 accumulate (stride-1 layers: %d forward and %d fused backward kernels; everything else "
                 "fp32 MFMA)" % split)
 

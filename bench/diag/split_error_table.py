@@ -3,7 +3,7 @@ same inputs: (1) every stride-1 layer shape of the network, forward kernel with 
 identity residual and statistics, batch 1024, and the fused backward kernel (data gradient and filter
 gradient) at batch 256; (2) a whole ResNet-20 training step at batch 256 and
 1024: loss and per-tensor gradient error. The rule the split path is held to: max error <= 2 x the
-exact path's."""
+exact path's. (3) The LeNet's second convolution: forward, data gradient and filter gradient kernels."""
 import sys
 
 import torch
@@ -97,4 +97,29 @@ for batch in (256, 1024):
     for k in ("fp32", "bf16x6", "torch fp32"):
         print(f"   {batch:<6d}  {k:<10s}  {rows[k][0]:.2e}     {rows[k][1]:.2e}       {rows[k][2]:.2e}")
     worst_ratio = max(worst_ratio, rows["bf16x6"][1] / rows["fp32"][1], rows["bf16x6"][2] / rows["fp32"][2])
+print("3. LeNet second convolution (5x5, 14x14, 32 -> 64), batch 1024: forward with bias + ReLU, data gradient, filter gradient (three seeds)")
+print("   kernel            exact fp32    bf16x6      ratio")
+e = {k: [0.0, 0.0] for k in ("forward", "data gradient", "filter gradient")}
+for seed in range(3):
+    b = 1024
+    x = T.rnd(b, 14, 14, 32, seed=3 + 10 * seed)
+    wt = T.rnd(5, 5, 32, 64, scale=0.05, seed=4 + 10 * seed)
+    bias = T.rnd(64, scale=0.3, seed=5 + 10 * seed)
+    dy = T.rnd(b, 14, 14, 64, seed=6 + 10 * seed)
+    xd, wd = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    pre = T.conv2d_same_unfold(xd, wd, 1)
+    want_y = torch.relu(pre + bias.double())
+    want_dx, want_dw = torch.autograd.grad(pre, (xd, wd), dy.double())
+    for i, split in enumerate((False, True)):
+        wf = nv.conv5x5_split_pack(wt) if split else nv.conv5x5_pack(wt)
+        wb = nv.conv5x5_split_pack(wt, flip=True) if split else wt
+        e["forward"][i] = max(e["forward"][i], T.rel(nv.conv5x5_tile(x, wf, bias=bias, split=split), want_y))
+        e["data gradient"][i] = max(e["data gradient"][i], T.rel(nv.conv5x5_tile(dy, wb, flip=True, split=split), want_dx))
+        ws = torch.empty(nv.conv5x5_wgrad_parts(b), 25 * 32 * 64, device="cuda")
+        dw = torch.zeros(5, 5, 32, 64, device="cuda")
+        nv.conv5x5_wgrad(x, dy, dw, partials=ws, split=split)
+        e["filter gradient"][i] = max(e["filter gradient"][i], T.rel(dw, want_dw))
+for k, (e32, esp) in e.items():
+    worst_ratio = max(worst_ratio, esp / e32)
+    print(f"   {k:<16s}  {e32:.3e}     {esp:.3e}   {esp / e32:.2f}")
 print(f"worst bf16x6 / exact ratio over everything above: {worst_ratio:.2f}  (rule: <= 2)")
