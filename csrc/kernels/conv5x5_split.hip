@@ -4,13 +4,13 @@
 // 2x2 max pool (forward) and fused pool + ReLU backward while staging (data gradient) as in the exact
 // kernel:
 //   * a workgroup's tile is one whole image: its zero-padded 18x18 input sits in LDS for all 25 taps as
-//     three bf16 planes (h, m, l parts; split while it is staged), pixels 96 bytes (32 channels) or 144
-//     bytes (64 channels) apart;
+//     three bf16 planes (h, m, l parts; split while it is staged), pixels 64 bytes (32 channels: 61 KB, two
+//     workgroups per CU, so one stages or pools while the other multiplies) or 144 bytes (64 channels) apart;
 //   * the filter is packed once per step into MFMA A fragments [tap][channel tile][K step][h, m, l][lane]
 //     (for the data gradient with the taps reversed and the channel roles swapped); a wave's fragments of
 //     a tap are three (six) 16-byte loads per lane straight from L2, fetched one tap ahead;
 //   * M = output channels, N = pixels: a lane ends up with 4 consecutive channels of one pixel; four pixel
-//     tiles run interleaved so that consecutive MFMAs write different accumulators (one wave per SIMD).
+//     tiles run interleaved so that consecutive MFMAs write different accumulators.
 // (reference: DistributedLeNet/src/mnist.py:119-123 and the conv2d_backprop_input of its gradient)
 #include "conv.h"
 #include "split_common.h"
@@ -49,7 +49,7 @@ template <int CIN, int COUT, int CSPLIT>
 struct S5 {
   static constexpr int CW = COUT / CSPLIT;           // output channels of one workgroup (blockIdx.y picks the slice)
   static constexpr int KS = CIN / 32;                // K = 32 steps per tap
-  static constexpr int PSB = CIN == 32 ? 96 : 144;   // bytes per pixel and plane: an odd number of 16-byte slots (+2, +1 of padding)
+  static constexpr int PSB = CIN == 32 ? 64 : 144;   // bytes per pixel and plane (64 channels: +1 sixteen-byte slot of padding)
   // (16 pixels across rows of 14 make about every second 16-lane group of a ds_read_b128 two-way
   // conflicted; 128 bytes of row padding remove that at 32 channels and change no measured time)
   static constexpr int ROWB = kPW * PSB;             // bytes per plane row
@@ -73,7 +73,7 @@ struct S5 {
 
 // x [B,14,14,CIN]; wpk: conv5x5_split_pack's output; y [B,14,14,COUT].
 template <int CIN, int COUT, bool BIAS_RELU, bool POOLED, bool POOLOUT, int CSPLIT>
-__global__ __launch_bounds__(256) void conv5x5_split_kernel(Conv5x5Args a) {
+__global__ __launch_bounds__(256, CIN == 32 ? 2 : 1) void conv5x5_split_kernel(Conv5x5Args a) {
   DTF_ABORT_GUARD(a);
   using G = S5<CIN, COUT, CSPLIT>;
   constexpr int KS = G::KS, PSB = G::PSB, ROWB = G::ROWB, PLANE = G::PLANE, NTW = G::NTW;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void conv5x5_split_kernel(Conv5x5Args a) {
       for (int part = 0; part < 3; ++part) wcur[ks][part] = wlane[(ks * 3 + part) * 64];
     // A tap is U units of (K step, group of up to four pixel tiles); the pixel-operand reads of the next unit -
     // the first unit of the next tap after a tap's last - are in flight while this unit's MFMAs run.
-    constexpr int kGroup = (KS * ((NTW + 3) / 4)) % 2 == 0 ? 4 : 2;
+    constexpr int kGroup = CIN == 32 ? 2 : ((KS * ((NTW + 3) / 4)) % 2 == 0 ? 4 : 2);
     constexpr int NG = (NTW + kGroup - 1) / kGroup;
     constexpr int U = KS * NG;
     static_assert(U % 2 == 0, "two operand buffers alternate with a fixed phase per tap");
@@ -557,7 +557,7 @@ void launch_s5(const Conv5x5Args& a, hipStream_t stream) {
     return true;
   }();
   (void)ready;
-  int cap = 256 / CSPLIT;   // one workgroup per CU
+  int cap = (CIN == 32 ? 512 : 256) / CSPLIT;
   const int iters = ceil_div(a.B, cap);
   const int grid = ceil_div(a.B, iters);
   launch("conv5x5_split", kernel, dim3(grid, CSPLIT), dim3(256), shmem, stream, a);
