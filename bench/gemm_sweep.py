@@ -11,7 +11,7 @@ from distributed_tensorflow_amd.ops import native as nv  # noqa: E402
 
 dev = "cuda"
 REP = 20
-NAMES = {1: "64x64x32g", 2: "128x128x32", 3: "64x64x128", 4: "64x128x64", 5: "128x128x64", 6: "64x64x64", 7: "64x64x64w8", 8: "64x64x128w8"}
+NAMES = {1: "64x64x32g", 2: "128x128x32", 3: "64x64x128", 4: "64x128x64", 5: "128x128x64", 6: "64x64x64", 7: "64x64x64w8", 8: "64x64x128w8", 9: "128x128x32p"}
 
 
 def timed(fn):
@@ -47,7 +47,7 @@ for b in batches:
         out = torch.zeros(m, n, device=dev)
         ref = (A.t() if ta else A) @ (B.t() if tb else B)
         res = []
-        for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8):
+        for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
             for splits in ((0,) if variant == 0 else (1, 2, 4, 8, 16, 32)):
                 try:
                     out.zero_()
@@ -62,5 +62,5 @@ for b in batches:
         auto = [r for r in res if r[1] == 0][0]
         print("batch %4d %s: auto %.1f us; best: " % (b, name, auto[0]) +
               ", ".join("%s/s%d %.1f us%s" % (NAMES[v], sp, t, "" if e < 1e-4 else " ERR %.1e" % e) for t, v, sp, e in res[:5] if v), flush=True)
-        for vv in (6, 7):
+        for vv in (6, 7, 9):
             print("      %s by splits: " % NAMES[vv] + ", ".join("s%d %.1f" % (sp, t) for t, v, sp, e in sorted(res, key=lambda r: r[2]) if v == vv), flush=True)

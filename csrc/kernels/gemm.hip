@@ -288,7 +288,108 @@ __global__ __launch_bounds__(256 * WK) void gemm_tile_kernel(GemmKArgs ka) {
       }
 }
 
+// 128x128 tile, 32-deep steps, eight waves (2 x 4, each 64 x 32 of the tile as 4 x 2 MFMA tiles), two LDS
+// stages: the LDS stores of step s + 1 and the global loads of step s + 2 are issued under the MFMAs of step
+// s, one barrier per step. A 64x64 tile pulls 32 KB through L2 per 0.5 MFLOP - at batch 1024 the fully
+// connected products move 205 MB in 47 us, 4.4 TB/s of L2 reads at 40 % MFMA busy; this tile needs half.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm_pipe_kernel(GemmKArgs ka) {
+  DTF_ABORT_GUARD(ka);
+  const GemmArgs& a = ka.g;
+  constexpr int PM = 128, PN = 128, PK = 32;
+  using TileA = OperandTile<PM, PK, !TA, 512>;
+  using TileB = OperandTile<PN, PK, TB, 512>;
+  constexpr int MI = 4, NJ = 2;
+  constexpr int STAGE = TileA::FLOATS + TileB::FLOATS;
+  extern __shared__ __attribute__((aligned(16))) float pipe_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, l15 = lane & 15;
+  const int per_xcd = (ka.total + 7) >> 3;   // as in gemm_tile_kernel: an XCD takes one contiguous range of work items
+  const int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (t >= ka.total) return;
+  const int tx = t % ka.gx, ty = (t / ka.gx) % ka.gy, tz = t / (ka.gx * ka.gy);
+  const int m0 = ty * PM, n0 = tx * PN;
+  const int k_begin = tz * ka.k_per_split;
+  int k_end = k_begin + ka.k_per_split;
+  if (k_end > a.K) k_end = a.K;
+  const int wm = (wave >> 2) * 64, wn = (wave & 3) * 32;
+
+  floatx4 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = floatx4{0, 0, 0, 0};
+
+  const int nsteps = k_end > k_begin ? (k_end - k_begin + PK - 1) / PK : 0;
+  float4 ra[TileA::NV], rb[TileB::NV];
+  if (nsteps > 0) {
+    TileA::fetch(a.A, a.lda, m0, a.M, k_begin, k_end, tid, ra);
+    TileB::fetch(a.B, a.ldb, n0, a.N, k_begin, k_end, tid, rb);
+    TileA::commit(pipe_smem, tid, ra);
+    TileB::commit(pipe_smem + TileA::FLOATS, tid, rb);
+    TileA::fetch(a.A, a.lda, m0, a.M, k_begin + PK, k_end, tid, ra);   // past k_end: zeros, never committed
+    TileB::fetch(a.B, a.ldb, n0, a.N, k_begin + PK, k_end, tid, rb);
+  }
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const float* As = pipe_smem + (s & 1) * STAGE;
+    const float* Bs = As + TileA::FLOATS;
+    if (s + 1 < nsteps) {
+      // every wave left the other stage at the barrier that ended step s - 1
+      float* An = pipe_smem + ((s + 1) & 1) * STAGE;
+      TileA::commit(An, tid, ra);
+      TileB::commit(An + TileA::FLOATS, tid, rb);
+      TileA::fetch(a.A, a.lda, m0, a.M, k_begin + (s + 2) * PK, k_end, tid, ra);
+      TileB::fetch(a.B, a.ldb, n0, a.N, k_begin + (s + 2) * PK, k_end, tid, rb);
+    }
+    const int k_left = k_end - (k_begin + s * PK);
+#pragma unroll
+    for (int kg = 0; kg < PK / 16; ++kg) {
+      if (kg * 16 >= k_left) break;   // a short last step: its empty groups hold zeros
+      floatx4 av[MI], bv[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) av[i] = TileA::frag(As, wm + i * 16 + l15, kg, q);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bv[j] = TileB::frag(Bs, wn + j * 16 + l15, kg, q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = DTF_MFMA16(av[i][e], bv[j][e], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm + i * 16 + 4 * q + r;
+        const int n = n0 + wn + j * 16 + l15;
+        if (m >= a.M || n >= a.N) continue;
+        float v = acc[i][j][r];
+        float* dst = a.C + (size_t)m * a.ldc + n;
+        if (ka.atomic_out) {
+          atomicAdd(dst, v);
+        } else {
+          if (a.bias) v += a.bias[n];
+          if (a.accumulate) v += *dst;
+          if (a.relu) v = fmaxf(v, 0.f);
+          *dst = v;
+        }
+      }
+}
+constexpr size_t kPipeLds = 2 * (128 * 36 + 128 * 36) * sizeof(float);   // the larger ([row][k]) layout for both operands
+
 using GemmKernel = void (*)(GemmKArgs);
+GemmKernel pipe_kernel(bool ta, bool tb) {
+  return ta ? (tb ? gemm_pipe_kernel<true, true> : gemm_pipe_kernel<true, false>)
+            : (tb ? gemm_pipe_kernel<false, true> : gemm_pipe_kernel<false, false>);
+}
 template <int TM_, int TN_, int TK_, int WK = 1>
 GemmKernel tile_kernel(bool ta, bool tb) {
   return ta ? (tb ? gemm_tile_kernel<TM_, TN_, TK_, true, true, WK> : gemm_tile_kernel<TM_, TN_, TK_, true, false, WK>)
@@ -316,7 +417,7 @@ void gemm_f32(const GemmArgs& a, hipStream_t stream) {
   const bool aligned = ((a.M | a.N | a.K | a.lda | a.ldb) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(a.B) & 15) == 0;
   // variant (0 = choose here): 1 general 64x64x32, 2 128x128x32, 3 64x64x128, 4 64x128x64, 5 128x128x64, 6 64x64x64,
-  // 7 64x64x64 with eight waves, 8 64x64x128 with eight waves
+  // 7 64x64x64 with eight waves, 8 64x64x128 with eight waves, 9 128x128x32 two-stage pipeline with eight waves
   // Measured on the fully connected products of the MNIST network (bench/gemm_sweep.py, batch 128
   // to 2048): the 64x64 tile with a 64-deep step is the fastest or within 5 % of it on every one
   // of them (20-30 % ahead of the 32-deep general kernel and, up to batch 2048, of the 128x128
@@ -326,10 +427,16 @@ void gemm_f32(const GemmArgs& a, hipStream_t stream) {
     // eight waves (7) where the tiles are few enough to leave a workgroup alone on its CU (the
     // batch <= 256 products: 3-8 % faster); with more tiles no different or slightly slower
     const int tiles64 = ceil_div(a.M, 64) * ceil_div(a.N, 64);
-    variant = ceil_div(a.M, TM) * ceil_div(a.N, TN) >= 512 ? 2 : tiles64 <= 200 ? 7 : 6;
+    const int tiles128 = ceil_div(a.M, TM) * ceil_div(a.N, TN);
+    variant = tiles128 >= 512 ? 2 : tiles64 <= 200 ? 7 : 6;
+    // about one 128x128 tile per CU and a short k: the two-stage pipeline without a split (the data gradient
+    // of the first fully connected layer at batch 1024: 42.5 against 47.7 us; slower than the 64x64 tiles
+    // wherever it needs a split to fill the CUs)
+    if (tiles128 >= 192 && tiles128 < 512 && a.K <= 1024) variant = 9;
   }
   if (!aligned) variant = 1;
   int bm, bn, bk, threads = 256;
+  size_t shmem = 0;
   GemmKernel kernel;
   switch (variant) {
     case 2: bm = 128; bn = 128; bk = 32; kernel = tile_kernel<128, 128, 32>(a.trans_a, a.trans_b); break;
@@ -339,6 +446,7 @@ void gemm_f32(const GemmArgs& a, hipStream_t stream) {
     case 6: bm = 64; bn = 64; bk = 64; kernel = tile_kernel<64, 64, 64>(a.trans_a, a.trans_b); break;
     case 7: bm = 64; bn = 64; bk = 64; kernel = tile_kernel<64, 64, 64, 2>(a.trans_a, a.trans_b); threads = 512; break;
     case 8: bm = 64; bn = 64; bk = 128; kernel = tile_kernel<64, 64, 128, 2>(a.trans_a, a.trans_b); threads = 512; break;
+    case 9: bm = 128; bn = 128; bk = 32; kernel = pipe_kernel(a.trans_a, a.trans_b); threads = 512; shmem = kPipeLds; break;
     default: variant = 1; bm = BM; bn = BN; bk = BK; kernel = gemm_kernel; break;
   }
   const int gx = ceil_div(a.N, bn), gy = ceil_div(a.M, bm);
@@ -348,6 +456,8 @@ void gemm_f32(const GemmArgs& a, hipStream_t stream) {
   } else if (variant == 1) {
     const int k_steps = ceil_div(a.K, BK);
     while (gx * gy * splits < 256 && splits * 2 <= k_steps / 4 && splits < 32) splits *= 2;
+  } else if (variant == 9 && a.variant == 0) {
+    splits = 1;
   } else {
     // Split along k until about four workgroups per CU exist (they hide each other's memory round
     // trips), while a split keeps at least three 64-deep steps' worth of k (192): below that the
@@ -358,6 +468,14 @@ void gemm_f32(const GemmArgs& a, hipStream_t stream) {
     while (gx * gy * splits < 1024 && a.K / (splits * 2) >= 192 && out * splits * 2 <= (8ll << 20) &&
            (a.accumulate || out <= 1200000 || gx * gy * splits < 256) && splits < 32)
       splits *= 2;
+  }
+  if (shmem) {
+    static const bool once = [] {
+      for (int ta = 0; ta < 2; ++ta)
+        for (int tb = 0; tb < 2; ++tb) ensure_dynamic_lds(reinterpret_cast<const void*>(pipe_kernel(ta, tb)), kPipeLds);
+      return true;
+    }();
+    (void)once;
   }
   GemmKArgs ka;
   ka.g = a;
@@ -376,7 +494,7 @@ void gemm_f32(const GemmArgs& a, hipStream_t stream) {
         for (int m = 0; m < a.M; ++m) memset_async(a.C + (size_t)m * a.ldc, 0, (size_t)a.N * sizeof(float), stream);
       }
     }
-    launch("gemm_f32_splitk", kernel, grid, dim3(threads), 0, stream, ka);
+    launch("gemm_f32_splitk", kernel, grid, dim3(threads), shmem, stream, ka);
     if (a.bias || a.relu) {
       BiasActArgs b{a.C, a.bias, a.M, a.N, a.ldc, a.relu};
       long long total = (long long)a.M * a.N;
@@ -385,7 +503,7 @@ void gemm_f32(const GemmArgs& a, hipStream_t stream) {
       launch("bias_act", bias_act_kernel, dim3(blocks), dim3(256), 0, stream, b);
     }
   } else {
-    launch("gemm_f32", kernel, grid, dim3(threads), 0, stream, ka);
+    launch("gemm_f32", kernel, grid, dim3(threads), shmem, stream, ka);
   }
 }
 

@@ -868,7 +868,7 @@ def test_gemm_variants(shape):
     close(out2 - 1, want_masked.sum(0))
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 8, 9])
 def test_gemm_tile_variants_and_splits(variant):
     """Every vector-load tile shape, with and without a k split whose last step is short, in all
     four operand layouts; the work-item-to-XCD mapping must cover every tile exactly once."""
