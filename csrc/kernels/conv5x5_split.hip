@@ -171,7 +171,6 @@ __global__ __launch_bounds__(256, CIN == 32 ? 2 : 1) void conv5x5_split_kernel(C
         if (tid + 256 * k < G::CHUNKS) put(sdst[k], pf[k]);
     }
     __syncthreads();
-    if (img + (int)gridDim.x < a.B) fetch(img + gridDim.x);
 
     floatx4 acc[MW][NTW];
 #pragma unroll
@@ -246,6 +245,10 @@ __global__ __launch_bounds__(256, CIN == 32 ? 2 : 1) void conv5x5_split_kernel(C
         for (int part = 0; part < 3; ++part) wcur[ks][part] = wnxt[ks][part];
       toff = toff_next;
     }
+
+    // The next image is requested here, not ahead of the tap loop: vector memory operations retire in order, so
+    // the first wait for a tap's filter fragments would also wait for these loads' trip to HBM.
+    if (img + (int)gridDim.x < a.B) fetch(img + gridDim.x);
 
     // lane holds output channels co0 + 4 q .. + 3 of pixel 16 t + n
     if constexpr (POOLOUT) __syncthreads();   // the input planes are about to be overwritten by the outputs
