@@ -61,7 +61,10 @@ struct BSplit {
   static_assert(PL::PLANE < 65536, "LDS offsets must fit 16 bits");
 };
 
-template <int C, int TW, int TH, bool DYBN, int RES>   // RES: 0 none, 1 identity shortcut, 2 option-A shortcut
+// RES: 0 none, 1 identity shortcut, 2 option-A shortcut. STAMPS: the timing instrumentation of
+// bench/diag/split_bwd_timeline.py, an instantiation of its own (in the production kernel its pointer and
+// counters cost seven spilled registers, each reloaded with a wait inside the band loop).
+template <int C, int TW, int TH, bool DYBN, int RES, bool STAMPS = false>
 __global__ __launch_bounds__(256, 2) void conv_bwd_split_kernel(ConvBwdFusedArgs a) {
   DTF_ABORT_GUARD(a);
   static_assert(!RES || DYBN, "the shortcut term rides on the BatchNorm prologue");
@@ -309,13 +312,18 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_split_kernel(ConvBwdFusedArgs
   auto band_loop = [&](auto&& phase) __attribute__((always_inline)) {
     int t_next = t + gpz;
     int band_no = 0;
-    unsigned long long* stamps = a.dbg_stamps ? a.dbg_stamps + ((size_t)blockIdx.x * 4 + wave) * 48 : nullptr;
+    unsigned long long* stamps = nullptr;
+    if constexpr (STAMPS) stamps = a.dbg_stamps ? a.dbg_stamps + ((size_t)blockIdx.x * 4 + wave) * 48 : nullptr;
     auto stamp = [&](int k) {   // timing experiments only (bench/diag/split_bwd_timeline.py)
-      if (stamps && lane == 0 && band_no < 7) stamps[band_no * 6 + k] = wall_clock64();
+      if constexpr (STAMPS) {
+        if (stamps && lane == 0 && band_no < 7) stamps[band_no * 6 + k] = wall_clock64();
+      }
     };
-    if (stamps && lane == 0) {   // where the wave runs: HW_ID (wave, SIMD, CU, SE) and XCC_ID, raw (bench/diag/wg_placement.py)
-      stamps[42] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-      stamps[43] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    if constexpr (STAMPS) {
+      if (stamps && lane == 0) {   // where the wave runs: HW_ID (wave, SIMD, CU, SE) and XCC_ID, raw (bench/diag/wg_placement.py)
+        stamps[42] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        stamps[43] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      }
     }
     while (t < total_tiles) {
       const int n = t / bands;
@@ -501,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_split_kernel(ConvBwdFusedArgs
 
 // copies != nullptr: no launch, *copies = workgroups per channel split (= copies of the gradient
 // filled through ConvBwdFusedArgs::dw_part)
-template <int C, int TW, int TH, bool DYBN, int RES = 0>
+template <int C, int TW, int TH, bool DYBN, int RES = 0, bool STAMPS = false>
 size_t launch_bs(const ConvBwdFusedArgs& a, hipStream_t stream, int* copies) {
   using G = BSplit<C, TW, TH>;
   const size_t shmem = (size_t)G::LDS_BYTES;
@@ -509,9 +517,9 @@ size_t launch_bs(const ConvBwdFusedArgs& a, hipStream_t stream, int* copies) {
   constexpr int zsplit = C / 16;
   const int total_tiles = (a.H / TH) * a.B;
   static const int bpc = [&] {
-    ensure_dynamic_lds(reinterpret_cast<const void*>(conv_bwd_split_kernel<C, TW, TH, DYBN, RES>), shmem);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(conv_bwd_split_kernel<C, TW, TH, DYBN, RES, STAMPS>), shmem);
     int n = 0;
-    DTF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_bwd_split_kernel<C, TW, TH, DYBN, RES>, 256, shmem));
+    DTF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_bwd_split_kernel<C, TW, TH, DYBN, RES, STAMPS>, 256, shmem));
     return n < 1 ? 1 : (n > 2 ? 2 : n);
   }();
   int gpz_max = (256 * bpc) / zsplit;
@@ -524,7 +532,7 @@ size_t launch_bs(const ConvBwdFusedArgs& a, hipStream_t stream, int* copies) {
     *copies = gpz;
     return 0;
   }
-  launch("conv_bwd_split", conv_bwd_split_kernel<C, TW, TH, DYBN, RES>, dim3(gpz * zsplit), dim3(256), shmem, stream, a);
+  launch("conv_bwd_split", conv_bwd_split_kernel<C, TW, TH, DYBN, RES, STAMPS>, dim3(gpz * zsplit), dim3(256), shmem, stream, a);
   return shmem;
 }
 
@@ -572,6 +580,10 @@ static size_t bs_dispatch(const ConvBwdFusedArgs& a, hipStream_t stream, int* co
       }
       if (a.C == 16) return launch_bs<16, 32, 4, true, 1>(a, stream, copies);
       return launch_bs<32, 16, 4, true, 1>(a, stream, copies);
+    }
+    if (a.dbg_stamps) {
+      if (a.C != 16) throw std::runtime_error("conv_bwd_split: timing stamps exist for the 16-channel BatchNorm-prologue kernel only");
+      return launch_bs<16, 32, 8, true, 0, true>(a, stream, copies);
     }
     if (a.C == 16) return launch_bs<16, 32, 8, true>(a, stream, copies);
     return launch_bs<32, 16, 8, true>(a, stream, copies);

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_split_kernel(ConvFpropArgs 
   using G = FSplit<CP, TW, TH>;
   constexpr int NT = G::NT, KS = G::KS, C4 = G::C4, LW = G::LW, PSB = G::PSB, ROWB = G::ROWB, PLANE = G::PLANE, P = G::P;
   constexpr bool STREAM = G::STREAM;
-  constexpr int WDEPTH = 3;          // K steps a streamed filter fragment is requested ahead of its use
+  constexpr int WDEPTH = 2;          // K steps a streamed filter fragment is requested ahead of its use
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   unsigned char* s_act = smem_b;                                        // [3][LH][ROWB], pixels PSB apart
   uintx4* s_wl = reinterpret_cast<uintx4*>(smem_b + 3 * PLANE);         // [KS][NT][64]
@@ -130,17 +130,14 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_split_kernel(ConvFpropArgs 
   };
 
   // ---- 3. per-thread halo geometry and the first tile -------------------------------------------------
-  int in_goff[G::NPF], in_loff[G::NPF], in_row[G::NPF];
-#pragma unroll
-  for (int k = 0; k < G::NPF; ++k) {
-    const int i = tid + k * 256;
-    const int c4 = i % C4;
-    const int r = (i / C4) / TW;
-    const int c = (i / C4) % TW + 1;
-    in_goff[k] = (r * a.W + (c - 1)) * CP + c4 * 4;
-    in_loff[k] = r * ROWB + c * PSB + c4 * 8;
-    in_row[k] = i < G::IN_CHUNKS ? r : -100000;
-  }
+  // chunk i = tid + 256 k of the tile: 256 chunks are RPK whole rows, so a thread's chunks keep their column
+  // and channel group and sit RPK rows apart - three registers instead of three per chunk
+  constexpr int RPK = 256 / (C4 * TW);
+  static_assert(256 % (C4 * TW) == 0, "256 chunks are whole rows");
+  const int in_r0 = (tid / C4) / TW;
+  const int in_goff0 = (in_r0 * a.W + (tid / C4) % TW) * CP + (tid % C4) * 4;
+  const int in_loff0 = in_r0 * ROWB + ((tid / C4) % TW + 1) * PSB + (tid % C4) * 8;
+  const int in_gstep = RPK * a.W * CP;
   // B-operand byte offset inside a plane = pixel-tile base (per lane, poff below) + channel slot of the
   // lane group + the K step's tap shift. The tap shift is a compile-time constant (an instruction
   // immediate) except with 16 channels, where lane groups 2-3 read the tap after that of groups 0-1:
@@ -167,10 +164,10 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_split_kernel(ConvFpropArgs 
     okbits = 0;
 #pragma unroll
     for (int k = 0; k < G::NPF; ++k) {
-      const int iy = base_row + in_row[k];
+      const int iy = base_row + in_r0 + RPK * k;
       floatx4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < a.H) {
-        v = *reinterpret_cast<const floatx4*>(in0 + in_goff[k]);
+      if (iy >= 0 && iy < a.H && tid + k * 256 < G::IN_CHUNKS) {
+        v = *reinterpret_cast<const floatx4*>(in0 + in_goff0 + k * in_gstep);
         okbits |= 1u << k;
       }
       pf[k] = v;
@@ -190,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_split_kernel(ConvFpropArgs 
         }
         uintx2 h, m, l;
         split3(v, h, m, l);
-        unsigned char* dst = s_act + in_loff[k];
+        unsigned char* dst = s_act + in_loff0 + k * (RPK * ROWB);
         *reinterpret_cast<uintx2*>(dst) = h;
         *reinterpret_cast<uintx2*>(dst + PLANE) = m;
         *reinterpret_cast<uintx2*>(dst + 2 * PLANE) = l;
@@ -242,15 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_split_kernel(ConvFpropArgs 
   }
   __syncthreads();
 
-  float e_scale[4], e_shift[4], e_mean[4], e_rstd[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int c = ct * 16 + 4 * q + r;
-    e_scale[r] = s_ebn[c];
-    e_shift[r] = s_ebn[NT * 16 + c];
-    e_mean[r] = s_ebn[2 * NT * 16 + c];
-    e_rstd[r] = s_ebn[3 * NT * 16 + c];
-  }
+  const float* e_lane = s_ebn + ct * 16 + 4 * q;   // this lane's four output channels in each coefficient row
   floatx4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};   // statistics of this wave's output-channel tile
 
   // pixel-tile base offsets (bytes) of this wave inside a plane
@@ -293,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_split_kernel(ConvFpropArgs 
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (t + gpz < total_tiles) load_tile(t + gpz);   // in flight during the MFMA phase
+    if (!STREAM && t + gpz < total_tiles) load_tile(t + gpz);   // in flight during the MFMA phase
 
     floatx4 acc[P];
 #pragma unroll
@@ -342,8 +331,24 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_split_kernel(ConvFpropArgs 
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp) wq[ks % WDEPTH][sp] = wfrag(ks + WDEPTH, sp);
       }
+      // streamed fragments: the next tile is requested behind the last MFMA step - ahead of the ring's requests,
+      // every wait for a fragment would also wait for the tile's trip to HBM (vector memory operations retire
+      // in order), and its registers would be live through the whole MFMA phase (64 channels: 8x8x64 forward
+      // 40.9 -> 31.0 us at batch 1024, 60 spilled registers -> 5, with the ring two deep instead of three)
+      if (STREAM && s == STEPS - 1) {
+        if (t + gpz < total_tiles) load_tile(t + gpz);
+      }
     }
 
+    // epilogue coefficients: read here, behind the MFMA phase, instead of living in registers through it
+    __builtin_amdgcn_sched_barrier(0);
+    const floatx4 e_scale = *reinterpret_cast<const floatx4*>(e_lane);
+    const floatx4 e_shift = *reinterpret_cast<const floatx4*>(e_lane + NT * 16);
+    floatx4 e_mean = {0.f, 0.f, 0.f, 0.f}, e_rstd = {0.f, 0.f, 0.f, 0.f};
+    if (BWD) {
+      e_mean = *reinterpret_cast<const floatx4*>(e_lane + 2 * NT * 16);
+      e_rstd = *reinterpret_cast<const floatx4*>(e_lane + 3 * NT * 16);
+    }
 #pragma unroll
     for (int i = 0; i < P; ++i) {
       const int p0 = (mg * P + i) * 16;
