@@ -257,8 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_split_kernel(ConvFpropArgs 
 
     write_tile();
     __syncthreads();
-    // streamed filter fragments: the first WDEPTH steps are requested before the next tile's loads,
-    // so that waiting for them does not wait for those
+    // streamed filter fragments: the first WDEPTH steps are requested here, the rest from inside the MFMA loop
     uintx4 wq[STREAM ? WDEPTH : 1][3];
     if (STREAM) {
 #pragma unroll
