@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_split_kernel(ConvFpropArgs 
       if (!STREAM) wl[buf] = s_wl[(ks * NT + ct) * 64 + lane];
     };
     read_step(0, 0);
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int s = 0; s < STEPS; ++s) {
       const int ks = s / PAIRS, pr = s % PAIRS, b = s & 1;
       if (s + 1 < STEPS) read_step(s + 1, b ^ 1);
