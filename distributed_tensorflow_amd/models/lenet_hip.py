@@ -31,8 +31,8 @@ class LeNetHipStep(StepProgramBase):
         nv.require()
         import os
 
-        # matmul="bf16x6" (or DTF_MATMUL): the second convolution's forward pass and data gradient run on
-        # the bf16 matrix pipe with fp32 operands split three ways and fp32 accumulation
+        # matmul="bf16x6" (or DTF_MATMUL): the second convolution's forward pass, data gradient and filter
+        # gradient run on the bf16 matrix pipe with fp32 operands split three ways and fp32 accumulation
         # (csrc/kernels/conv5x5_split.hip); opt-in, everything else stays on the exact-fp32 instruction
         self.matmul = matmul or os.environ.get("DTF_MATMUL", "fp32")
         if self.matmul not in ("fp32", "bf16x6"):
