@@ -246,7 +246,8 @@ struct Conv5x5PackArgs {
   int Cin, Cout;
   int flip;         // conv5x5_split_pack only: pack the data-gradient operand (taps reversed, channel roles swapped)
 };
-// Opt-in split-operand ("bf16x6") form of conv5x5_tile, forward and data gradient (conv5x5_split.hip):
+// Opt-in split-operand ("bf16x6") form of conv5x5_tile, forward and data gradient (conv5x5_split.hip;
+// the filter gradient's form is conv5x5_wgrad_split below):
 // `w` is then conv5x5_split_pack's output for the same direction (float-typed storage of
 // conv5x5_split_packed_floats() elements holding bf16 values), `imgs` is ignored.
 void conv5x5_split(const Conv5x5Args& a, hipStream_t stream);

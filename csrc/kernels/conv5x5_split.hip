@@ -1,5 +1,5 @@
-// The LeNet's second convolution (5x5, SAME, 14x14 maps, 32 -> 64 channels; conv5x5_tile.hip) and its data
-// gradient on the bf16 matrix pipe with fp32 operands split three ways ("bf16x6", conv_fprop_split.hip):
+// The LeNet's second convolution (5x5, SAME, 14x14 maps, 32 -> 64 channels; conv5x5_tile.hip), its data
+// gradient and (further down) its filter gradient on the bf16 matrix pipe with fp32 operands split three ways ("bf16x6", conv_fprop_split.hip):
 // six v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation. Opt-in; tile walk, fused bias + ReLU +
 // 2x2 max pool (forward) and fused pool + ReLU backward while staging (data gradient) as in the exact
 // kernel:
@@ -9,8 +9,9 @@
 //   * the filter is packed once per step into MFMA A fragments [tap][channel tile][K step][h, m, l][lane]
 //     (for the data gradient with the taps reversed and the channel roles swapped); a wave's fragments of
 //     a tap are three (six) 16-byte loads per lane straight from L2, fetched one tap ahead;
-//   * M = output channels, N = pixels: a lane ends up with 4 consecutive channels of one pixel; four pixel
-//     tiles run interleaved so that consecutive MFMAs write different accumulators.
+//   * M = output channels, N = pixels: a lane ends up with 4 consecutive channels of one pixel; a wave owns
+//     two output-channel tiles and walks groups of pixel tiles, so every pixel-operand read feeds twelve
+//     MFMAs and consecutive MFMAs write different accumulators.
 // (reference: DistributedLeNet/src/mnist.py:119-123 and the conv2d_backprop_input of its gradient)
 #include "conv.h"
 #include "split_common.h"
